@@ -1,0 +1,124 @@
+"""ctypes binding of libadsb_hip.so (include/adsb_hip.h, include/adsb_host.h).
+
+There is no CPU fallback: if the HIP library has not been built this module raises, and without
+a HIP device ``adsb_create`` returns ADSB_E_NODEVICE.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libadsb_hip.so")
+
+ADSB_ABI_VERSION = 1
+ADSB_OK = 0
+ADSB_E_SHORT = -1
+ADSB_E_ARG = -2
+ADSB_E_CAPACITY = -3
+ADSB_E_NOMEM = -4
+ADSB_E_NODEVICE = -5
+ADSB_E_STATE = -6
+ADSB_FLAG_TRUNCATED = 0x1
+ADSB_SAMPLE_I8 = 0
+ADSB_SAMPLE_I16 = 1
+ADSB_MSG_AIRCRAFT_ID, ADSB_MSG_AIRCRAFT_POSITION, ADSB_MSG_UNKNOWN = 0, 1, 2
+
+
+class AdsbFrame(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("bytes", C.c_uint8 * 14), ("status", C.c_uint8),
+                ("fixed_bit", C.c_uint8)]
+
+
+class AdsbCfg(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("sample_type", C.c_int32),
+                ("max_channels", C.c_uint32), ("max_samples", C.c_uint64), ("max_out", C.c_uint64),
+                ("stream", C.c_void_p), ("host_staging", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class AdsbSynthCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("slot_len", C.c_uint32), ("frame_pct", C.c_uint32),
+                ("pct_flip_data", C.c_uint32), ("pct_flip_crc", C.c_uint32),
+                ("pct_flip_two", C.c_uint32), ("noise_div", C.c_uint32), ("amp_shift", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class AdsbPacketView(C.Structure):
+    _fields_ = [("packet", C.c_uint8 * 14), ("downlink_format", C.c_uint8), ("capability", C.c_uint8),
+                ("icao", C.c_uint32), ("msg_type", C.c_uint8), ("msg_kind", C.c_int32),
+                ("callsign", C.c_char * 9), ("surveillance_status", C.c_uint8),
+                ("nic_supplement", C.c_uint8), ("altitude", C.c_int32), ("cpr_time", C.c_uint8),
+                ("cpr_odd", C.c_uint8), ("cpr_latitude", C.c_uint32), ("cpr_longitude", C.c_uint32),
+                ("raw_msg", C.c_uint8 * 10)]
+
+
+# name -> (restype, argtypes); every function include/*.h declares
+_P = C.POINTER
+PROTOTYPES = {
+    "adsb_create": (C.c_int, [_P(AdsbCfg), _P(C.c_void_p)]),
+    "adsb_destroy": (None, [C.c_void_p]),
+    "adsb_strerror": (C.c_char_p, [C.c_int]),
+    "adsb_demod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _P(AdsbFrame), C.c_size_t,
+                             _P(C.c_size_t), _P(C.c_uint32)]),
+    "adsb_demod_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_size_t]),
+    "adsb_fetch": (C.c_int, [C.c_void_p, _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint64),
+                             _P(C.c_uint64), _P(C.c_uint32)]),
+    "adsb_fetch_counts": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint32)]),
+    "adsb_result_device": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p)]),
+    "adsb_stream": (C.c_void_p, [C.c_void_p]),
+    "adsb_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "adsb_timing_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_uint32)]),
+    "adsb_time_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, _P(C.c_double)]),
+    "adsb_debug_magnitudes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adsb_debug_mag_mode": (C.c_int, [C.c_void_p]),
+    "adsb_synth_default": (None, [_P(AdsbSynthCfg)]),
+    "adsb_synth_fill_host": (C.c_int, [_P(AdsbSynthCfg), C.c_int, C.c_uint32, C.c_uint64, C.c_size_t,
+                                       C.c_void_p]),
+    "adsb_synth_fill_device": (C.c_int, [C.c_void_p, _P(AdsbSynthCfg), C.c_uint32, C.c_uint64,
+                                         C.c_size_t, C.c_void_p]),
+    "adsb_synth_slot": (C.c_int, [_P(AdsbSynthCfg), C.c_uint32, C.c_uint64, _P(C.c_uint64),
+                                  _P(C.c_uint8 * 14), _P(C.c_uint8 * 14), _P(C.c_int)]),
+    # include/adsb_host.h
+    "adsb_packet_new": (C.c_int, [_P(C.c_uint8 * 14), _P(AdsbPacketView)]),
+    "adsb_packet_new_from_string": (C.c_int, [C.c_char_p, _P(AdsbPacketView)]),
+    "adsb_packet_display": (C.c_size_t, [_P(C.c_uint8 * 14), C.c_char_p, C.c_char_p, C.c_size_t]),
+    "adsb_pipeline_playback": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t,
+                                         _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint64),
+                                         C.c_char_p, C.c_size_t, _P(C.c_size_t)]),
+    "adsb_load_c16": (C.c_int, [C.c_char_p, _P(_P(C.c_int16)), _P(C.c_size_t)]),
+    "adsb_save_c16": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
+    "adsb_free": (None, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with ./build.sh (or __graft_entry__.build()). "
+            "air_rs_amd has no CPU fallback for the demodulation path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(code):
+    return load().adsb_strerror(int(code)).decode()
+
+
+class AdsbError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = int(code)
+        super().__init__(f"{where}: {strerror(code)} (code {int(code)})")
+
+
+def check(code, where=""):
+    if code != ADSB_OK:
+        raise AdsbError(code, where)

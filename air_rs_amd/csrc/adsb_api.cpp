@@ -1,0 +1,511 @@
+// adsb_api.cpp -- the extern "C" boundary (include/adsb_hip.h) over the gfx950 kernels.
+//
+// Replaces, per received buffer, the body of the reference's thread 2 loop
+// (src/adsb.rs:95-116).  There is NO CPU fallback: without a HIP device adsb_create() fails with
+// ADSB_E_NODEVICE and every other entry point needs a context.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "adsb_kernels.h"
+#include "adsb_synth.h"
+
+using adsbk::kTile;
+using adsbk::kWindow;
+
+namespace {
+constexpr int kTimingRing = 512;
+}
+
+struct adsb_ctx {
+    adsb_cfg cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int mag_mode = 0;
+    uint32_t bps = 2; // bytes per IQ sample
+
+    // device buffers
+    void *staging = nullptr;        // host-fed input (cfg.host_staging)
+    adsbk::Seg *seg = nullptr;      // [n_tiles_max]
+    uint32_t *out_start = nullptr;  // [n_tiles_max + 1]
+    uint64_t *chan_counts = nullptr;// [max_channels]
+    adsb_frame *slots = nullptr;    // [cap_slots]
+    adsb_frame *out = nullptr;      // [max_out]
+    adsbk::Header *hdr = nullptr;
+    uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
+    uint32_t cap_slots = 0;
+    uint32_t n_tiles_max = 0;
+
+    // pinned host mirrors
+    adsbk::Header *hdr_host = nullptr;
+
+    // last launch
+    bool launched = false;
+    const void *last_iq = nullptr;
+    uint32_t last_channels = 0;
+    uint64_t last_samples = 0, last_stride = 0;
+    uint32_t last_tpc = 0, last_tiles = 0;
+
+    // timing
+    bool timing = false;
+    hipEvent_t ev[kTimingRing][3] = {};
+    bool ev_made = false;
+    uint32_t ev_count = 0;
+};
+
+#define HIPCHK(x)                                  \
+    do {                                           \
+        hipError_t e_ = (x);                       \
+        if (e_ != hipSuccess) return (int)e_;      \
+    } while (0)
+
+static uint32_t tiles_for(uint64_t n_samples)
+{
+    if (n_samples <= (uint64_t)kWindow) return 0;
+    uint64_t n_off = n_samples - kWindow;
+    return (uint32_t)((n_off + kTile - 1) / kTile);
+}
+
+extern "C" const char *adsb_strerror(int code)
+{
+    switch (code) {
+    case ADSB_OK: return "ok";
+    case ADSB_E_SHORT: return "buffer shorter than 240 samples (reference panics, adsb.rs:98)";
+    case ADSB_E_ARG: return "bad argument";
+    case ADSB_E_CAPACITY: return "exceeds the capacity the context was created with";
+    case ADSB_E_NOMEM: return "out of memory";
+    case ADSB_E_NODEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case ADSB_E_STATE: return "call sequence error";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+extern "C" void adsb_destroy(adsb_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev_made)
+        for (auto &e : c->ev)
+            for (auto &x : e)
+                if (x) (void)hipEventDestroy(x);
+    (void)hipFree(c->staging);
+    (void)hipFree(c->seg);
+    (void)hipFree(c->out_start);
+    (void)hipFree(c->chan_counts);
+    (void)hipFree(c->slots);
+    (void)hipFree(c->out);
+    (void)hipFree(c->hdr);
+    (void)hipFree(c->scratch);
+    if (c->hdr_host) (void)hipHostFree(c->hdr_host);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
+{
+    if (!cfg || !out_ctx) return ADSB_E_ARG;
+    *out_ctx = nullptr;
+    if (cfg->abi_version != ADSB_ABI_VERSION) return ADSB_E_ARG;
+    if (cfg->sample_type != ADSB_SAMPLE_I8 && cfg->sample_type != ADSB_SAMPLE_I16) return ADSB_E_ARG;
+    if (cfg->max_channels == 0 || cfg->max_samples == 0 || cfg->max_out == 0) return ADSB_E_ARG;
+    if (cfg->max_out > 0x7FFFFFFFull - kTile) return ADSB_E_ARG;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return ADSB_E_NODEVICE;
+    if (hipSetDevice(cfg->device) != hipSuccess) return ADSB_E_NODEVICE;
+
+    adsb_ctx *c = new (std::nothrow) adsb_ctx();
+    if (!c) return ADSB_E_NOMEM;
+    c->cfg = *cfg;
+    c->bps = cfg->sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
+    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples) * cfg->max_channels;
+    if (tiles == 0) tiles = 1;
+    if (tiles > 0x7FFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
+    c->n_tiles_max = (uint32_t)tiles;
+    c->cap_slots = (uint32_t)(cfg->max_out + kTile);
+
+    int rc = ADSB_OK;
+    auto fail = [&](int code) { rc = code; };
+    do {
+        if (cfg->stream) {
+            c->stream = (hipStream_t)cfg->stream;
+        } else {
+            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
+            c->own_stream = true;
+        }
+        hipError_t e = hipSuccess;
+        if (cfg->host_staging) {
+            // +64 bytes so the staging base keeps 16-byte alignment for any channel stride rounding
+            uint64_t stride = (cfg->max_samples + 7) & ~7ull;
+            e = hipMalloc(&c->staging, stride * cfg->max_channels * c->bps + 64);
+            if (e != hipSuccess) { fail(ADSB_E_NOMEM); break; }
+        }
+        if ((e = hipMalloc((void **)&c->seg, sizeof(adsbk::Seg) * (size_t)c->n_tiles_max)) != hipSuccess ||
+            (e = hipMalloc((void **)&c->out_start, sizeof(uint32_t) * ((size_t)c->n_tiles_max + 1))) != hipSuccess ||
+            (e = hipMalloc((void **)&c->chan_counts, sizeof(uint64_t) * cfg->max_channels)) != hipSuccess ||
+            (e = hipMalloc((void **)&c->slots, sizeof(adsb_frame) * (size_t)c->cap_slots)) != hipSuccess ||
+            (e = hipMalloc((void **)&c->out, sizeof(adsb_frame) * (size_t)cfg->max_out)) != hipSuccess ||
+            (e = hipMalloc((void **)&c->hdr, sizeof(adsbk::Header))) != hipSuccess ||
+            (e = hipMalloc((void **)&c->scratch, 64)) != hipSuccess) {
+            fail(ADSB_E_NOMEM);
+            break;
+        }
+        if (hipHostMalloc((void **)&c->hdr_host, sizeof(adsbk::Header), hipHostMallocDefault) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
+        if (hipMemsetAsync(c->hdr, 0, sizeof(adsbk::Header), c->stream) != hipSuccess ||
+            hipMemsetAsync(c->scratch, 0, 64, c->stream) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
+        uint32_t probe[4] = {0, 0, 0, 0};
+        e = adsbk::probe_cvt(c->stream, c->scratch, probe);
+        if (e != hipSuccess) { fail((int)e); break; }
+        // expected truncation of {0.75, 2.5, 180.9986} = {0, 2, 180}
+        const uint32_t want = 0u | (2u << 8) | (180u << 16);
+        if (probe[0] == want) c->mag_mode = 0;
+        else if (probe[1] == want) c->mag_mode = 1;
+        else c->mag_mode = 2;
+        if (const char *force = getenv("ADSB_FORCE_MAG_MODE")) c->mag_mode = atoi(force) % 3;
+    } while (0);
+    if (rc != ADSB_OK) { adsb_destroy(c); return rc; }
+    *out_ctx = c;
+    return ADSB_OK;
+}
+
+extern "C" void *adsb_stream(adsb_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
+
+static adsbk::DemodArgs demod_args(adsb_ctx *c, uint32_t tile_first)
+{
+    adsbk::DemodArgs a{};
+    a.iq = c->last_iq;
+    a.n_samples = c->last_samples;
+    a.channel_stride = c->last_stride;
+    a.tiles_per_channel = c->last_tpc;
+    a.tile_first = tile_first;
+    a.seg = c->seg;
+    a.slots = c->slots;
+    a.cap_slots = c->cap_slots;
+    a.hdr = c->hdr;
+    return a;
+}
+
+static adsbk::CompactArgs compact_args(adsb_ctx *c, uint32_t tile_first, uint32_t tile_count)
+{
+    adsbk::CompactArgs a{};
+    a.seg = c->seg;
+    a.slots = c->slots;
+    a.out_start = c->out_start;
+    a.chan_counts = c->chan_counts;
+    a.out = c->out;
+    a.n_tiles = c->last_tiles;
+    a.tiles_per_channel = c->last_tpc;
+    a.n_channels = c->last_channels;
+    a.max_out = (uint32_t)c->cfg.max_out;
+    a.tile_first = tile_first;
+    a.tile_count = tile_count;
+    a.hdr = c->hdr;
+    return a;
+}
+
+extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t n_channels,
+                                       size_t n_samples, size_t channel_stride)
+{
+    if (!c || !iq_dev || n_channels == 0) return ADSB_E_ARG;
+    if (n_samples < (size_t)kWindow) return ADSB_E_SHORT;
+    if (n_channels > c->cfg.max_channels || n_samples > c->cfg.max_samples) return ADSB_E_CAPACITY;
+    if (((uintptr_t)iq_dev & 15u) != 0) return ADSB_E_ARG;
+    if (n_channels > 1 && (channel_stride < n_samples || (channel_stride & 7u) != 0)) return ADSB_E_ARG;
+    if (n_channels == 1) channel_stride = n_samples;
+    HIPCHK(hipSetDevice(c->cfg.device));
+
+    c->last_iq = iq_dev;
+    c->last_channels = n_channels;
+    c->last_samples = n_samples;
+    c->last_stride = channel_stride;
+    c->last_tpc = tiles_for(n_samples);
+    c->last_tiles = c->last_tpc * n_channels;
+    c->launched = true;
+
+    hipEvent_t *ev = nullptr;
+    if (c->timing) {
+        if (!c->ev_made) {
+            for (auto &e : c->ev)
+                for (auto &x : e) HIPCHK(hipEventCreate(&x));
+            c->ev_made = true;
+        }
+        ev = c->ev[c->ev_count % kTimingRing];
+        HIPCHK(hipEventRecord(ev[0], c->stream));
+    }
+    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, 0), c->last_tiles));
+    if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
+    adsbk::CompactArgs ca = compact_args(c, 0, c->last_tiles);
+    HIPCHK(adsbk::launch_scan(c->stream, ca));
+    HIPCHK(adsbk::launch_gather(c->stream, ca));
+    if (ev) {
+        HIPCHK(hipEventRecord(ev[2], c->stream));
+        c->ev_count++;
+    }
+    return ADSB_OK;
+}
+
+// Slot-store overflow (far more gate survivors than max_out + one tile): redo the tiles that feed
+// the first max_out frames in batches whose survivors fit.  Counts from the first pass are exact,
+// so the plan is made on the host.  Only pathological inputs get here.
+static int rerun_in_batches(adsb_ctx *c)
+{
+    const uint32_t n = c->last_tiles;
+    std::vector<adsbk::Seg> seg(n);
+    std::vector<uint32_t> start((size_t)n + 1);
+    HIPCHK(hipMemcpyAsync(seg.data(), c->seg, sizeof(adsbk::Seg) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(start.data(), c->out_start, sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t limit = 0;
+    while (limit < n && start[limit] < (uint32_t)c->cfg.max_out) ++limit;
+    uint32_t t0 = 0;
+    while (t0 < limit) {
+        uint64_t used = 0;
+        uint32_t t1 = t0;
+        while (t1 < limit && used + seg[t1].cand <= c->cap_slots) used += seg[t1++].cand;
+        if (t1 == t0) return ADSB_E_STATE; // a single tile never exceeds cap_slots (>= kTile)
+        HIPCHK(hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream));
+        HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, t0), t1 - t0));
+        HIPCHK(adsbk::launch_gather(c->stream, compact_args(c, t0, t1 - t0)));
+        t0 = t1;
+    }
+    HIPCHK(hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(&c->hdr->retry, 0, sizeof(uint32_t), c->stream));
+    return ADSB_OK;
+}
+
+static int sync_header(adsb_ctx *c)
+{
+    if (!c->launched) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpyAsync(c->hdr_host, c->hdr, sizeof(adsbk::Header), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->hdr_host->retry) {
+        int rc = rerun_in_batches(c);
+        if (rc != ADSB_OK) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->hdr_host->retry = 0;
+    }
+    return ADSB_OK;
+}
+
+extern "C" int adsb_fetch_counts(adsb_ctx *c, uint64_t *n_out, uint64_t *total_found, uint32_t *flags)
+{
+    if (!c) return ADSB_E_ARG;
+    int rc = sync_header(c);
+    if (rc != ADSB_OK) return rc;
+    if (n_out) *n_out = c->hdr_host->n_out;
+    if (total_found) *total_found = c->hdr_host->total_found;
+    if (flags) *flags = c->hdr_host->flags;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_fetch(adsb_ctx *c, adsb_frame *out, size_t max_out, size_t *n_out,
+                          uint64_t *per_channel_counts, uint64_t *total_found, uint32_t *flags)
+{
+    if (!c || !n_out || (!out && max_out)) return ADSB_E_ARG;
+    int rc = sync_header(c);
+    if (rc != ADSB_OK) return rc;
+    uint64_t n = c->hdr_host->n_out;
+    uint32_t fl = c->hdr_host->flags;
+    if (n > max_out) { n = max_out; fl |= ADSB_FLAG_TRUNCATED; }
+    if (n) HIPCHK(hipMemcpyAsync(out, c->out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint64_t> cc;
+    if (per_channel_counts) {
+        HIPCHK(hipMemcpyAsync(per_channel_counts, c->chan_counts, sizeof(uint64_t) * c->last_channels,
+                              hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (per_channel_counts && n < c->hdr_host->n_out) { // caller's array was the tighter cap
+        uint64_t left = n;
+        for (uint32_t k = 0; k < c->last_channels; ++k) {
+            uint64_t take = std::min(per_channel_counts[k], left);
+            per_channel_counts[k] = take;
+            left -= take;
+        }
+    }
+    *n_out = (size_t)n;
+    if (total_found) *total_found = c->hdr_host->total_found;
+    if (flags) *flags = fl;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_result_device(adsb_ctx *c, const adsb_frame **frames_dev, const void **header_dev)
+{
+    if (!c) return ADSB_E_ARG;
+    if (frames_dev) *frames_dev = c->out;
+    if (header_dev) *header_dev = c->hdr;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_demod(adsb_ctx *c, const void *iq, size_t n_samples, adsb_frame *out,
+                          size_t max_out, size_t *n_out, uint32_t *flags)
+{
+    if (!c || !iq || !n_out) return ADSB_E_ARG;
+    *n_out = 0;
+    if (flags) *flags = 0;
+    if (!c->staging) return ADSB_E_STATE;
+    if (n_samples < (size_t)kWindow) return ADSB_E_SHORT;
+    if (n_samples > c->cfg.max_samples) return ADSB_E_CAPACITY;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpyAsync(c->staging, iq, n_samples * c->bps, hipMemcpyHostToDevice, c->stream));
+    int rc = adsb_demod_device_async(c, c->staging, 1, n_samples, n_samples);
+    if (rc != ADSB_OK) return rc;
+    return adsb_fetch(c, out, max_out, n_out, nullptr, nullptr, flags);
+}
+
+// ---- measurement / test helpers -----------------------------------------------------------------
+extern "C" int adsb_timing_enable(adsb_ctx *c, int on)
+{
+    if (!c) return ADSB_E_ARG;
+    c->timing = on != 0;
+    c->ev_count = 0;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_timing_read(adsb_ctx *c, double *demod_ms, double *order_ms, uint32_t *n_launches)
+{
+    if (!c) return ADSB_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t n = std::min<uint32_t>(c->ev_count, kTimingRing);
+    double a = 0, b = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        float x = 0, y = 0;
+        HIPCHK(hipEventElapsedTime(&x, c->ev[k][0], c->ev[k][1]));
+        HIPCHK(hipEventElapsedTime(&y, c->ev[k][1], c->ev[k][2]));
+        a += x;
+        b += y;
+    }
+    if (demod_ms) *demod_ms = n ? a / n : 0.0;
+    if (order_ms) *order_ms = n ? b / n : 0.0;
+    if (n_launches) *n_launches = n;
+    c->ev_count = 0;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_time_read_ceiling(adsb_ctx *c, const void *buf_dev, size_t bytes, int iters,
+                                      double *ms_per_pass)
+{
+    if (!c || !buf_dev || iters <= 0 || !ms_per_pass || ((uintptr_t)buf_dev & 15u)) return ADSB_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(adsbk::launch_read_only(c->stream, buf_dev, bytes, c->scratch + 8)); // warm-up
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int k = 0; k < iters; ++k) HIPCHK(adsbk::launch_read_only(c->stream, buf_dev, bytes, c->scratch + 8));
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_pass = (double)ms / iters;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_debug_magnitudes(adsb_ctx *c, const void *iq_host, size_t n, uint16_t *mags_host)
+{
+    if (!c || !iq_host || !mags_host) return ADSB_E_ARG;
+    if (n == 0) return ADSB_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    void *d_in = nullptr;
+    uint16_t *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_in, n * c->bps + 16));
+    hipError_t e = hipMalloc((void **)&d_out, n * sizeof(uint16_t));
+    if (e != hipSuccess) { (void)hipFree(d_in); return (int)e; }
+    int rc = ADSB_OK;
+    do {
+        if ((e = hipMemcpyAsync(d_in, iq_host, n * c->bps, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+        if ((e = adsbk::launch_magnitudes(c->stream, c->cfg.sample_type, c->mag_mode, d_in, n, d_out)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(mags_host, d_out, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    if (e != hipSuccess) rc = (int)e;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+// ---- synthetic source ------------------------------------------------------------------------------
+extern "C" void adsb_synth_default(adsb_synth_cfg *s)
+{
+    if (!s) return;
+    std::memset(s, 0, sizeof(*s));
+    s->seed = 0x0AD5B0001ull;
+    s->slot_len = 2000;  // one frame slot per millisecond of 2 MSPS signal
+    s->frame_pct = 100;
+    s->pct_flip_data = 5;
+    s->pct_flip_crc = 2;
+    s->pct_flip_two = 3;
+    s->noise_div = 18;   // Irwin-Hall(4 bytes)/18: sigma ~ 8.2 LSB
+    s->amp_shift = 0;
+}
+
+static bool synth_ok(const adsb_synth_cfg *s)
+{
+    return s && s->slot_len >= 256 && s->frame_pct <= 100 && s->noise_div >= 1 && s->amp_shift <= 7 &&
+           s->pct_flip_data + s->pct_flip_crc + s->pct_flip_two <= 100;
+}
+
+extern "C" int adsb_synth_slot(const adsb_synth_cfg *cfg, uint32_t channel, uint64_t slot,
+                               uint64_t *start, uint8_t clean14[14], uint8_t sent14[14], int *kind)
+{
+    if (!synth_ok(cfg)) return ADSB_E_ARG;
+    adsb_synth::Slot s;
+    adsb_synth::slot_params(*cfg, channel, slot, s);
+    if (start) *start = slot * (uint64_t)cfg->slot_len + s.jitter;
+    if (clean14) std::memcpy(clean14, s.clean, 14);
+    if (sent14) std::memcpy(sent14, s.sent, 14);
+    if (kind) *kind = s.kind;
+    return s.present ? 1 : 0;
+}
+
+extern "C" int adsb_synth_fill_host(const adsb_synth_cfg *cfg, int sample_type, uint32_t channel,
+                                    uint64_t first, size_t n, void *iq)
+{
+    if (!synth_ok(cfg) || (!iq && n) || (sample_type != ADSB_SAMPLE_I8 && sample_type != ADSB_SAMPLE_I16))
+        return ADSB_E_ARG;
+    int8_t *o8 = (int8_t *)iq;
+    int16_t *o16 = (int16_t *)iq;
+    uint64_t cur_slot = ~0ull;
+    adsb_synth::Slot s{};
+    for (size_t j = 0; j < n; ++j) {
+        const uint64_t k = first + j;
+        const uint64_t slot = k / cfg->slot_len;
+        if (slot != cur_slot) {
+            adsb_synth::slot_params(*cfg, channel, slot, s);
+            cur_slot = slot;
+        }
+        int vi, vq;
+        adsb_synth::sample_iq(*cfg, channel, k, s, slot, vi, vq);
+        if (sample_type == ADSB_SAMPLE_I8) {
+            o8[2 * j] = (int8_t)adsb_synth::clip8(vi);
+            o8[2 * j + 1] = (int8_t)adsb_synth::clip8(vq);
+        } else {
+            int wi = vi << cfg->amp_shift, wq = vq << cfg->amp_shift;
+            wi = wi < -32768 ? -32768 : (wi > 32767 ? 32767 : wi);
+            wq = wq < -32768 ? -32768 : (wq > 32767 ? 32767 : wq);
+            o16[2 * j] = (int16_t)wi;
+            o16[2 * j + 1] = (int16_t)wq;
+        }
+    }
+    return ADSB_OK;
+}
+
+extern "C" int adsb_synth_fill_device(adsb_ctx *c, const adsb_synth_cfg *cfg, uint32_t channel,
+                                      uint64_t first, size_t n, void *iq_dev)
+{
+    if (!c || !synth_ok(cfg) || (!iq_dev && n)) return ADSB_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(adsbk::launch_synth(c->stream, *cfg, c->cfg.sample_type, channel, first, n, iq_dev));
+    return ADSB_OK;
+}

@@ -1,0 +1,719 @@
+// adsb_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for the air_rs IQ -> packet path.
+//
+// What the reference computes per received buffer (src/adsb.rs:95-116), in closed form:
+//   m[k]   = floor(sqrt(I^2+Q^2))                                  (src/utils.rs:46-52)
+//   gate(i)= min m[i+{0,2,7,9}] >= max m[i+{1,3,4,5,6,8,10..15}]   (src/adsb/demod.rs:23-36)
+//            && min m[i+16+{0,3,5,7,8}] >= max m[i+16+{1,2,4,6,9}] (src/adsb/demod.rs:45-54)
+//   bit_k  = m[i+16+2k] > m[i+17+2k], k = 0..111, MSB first        (demod.rs:92-131,180-201)
+//   s      = CRC24(bytes[0..11]) ^ bytes[11..14]                   (src/adsb/crc.rs:10-40)
+//   emit at every i in [0, N-240) where gate(i) and (s == 0 or s is the syndrome of one of the
+//   88 data bits, which is then flipped)                            (src/adsb/crc.rs:49-65)
+// Every offset is independent (the `_i += 240` at adsb.rs:113 has no effect).
+//
+// Mapping to the machine (no MFMA: this is an HBM-bound stencil + sparse decode):
+//   * one workgroup = one tile of kTile offsets; the tile's raw IQ is read once, coalesced,
+//     16 B per lane through a bounds-checked buffer descriptor (tails read as zero);
+//   * magnitudes are produced in registers (v_dot4_i32_i8 -> v_sqrt_f32 -> v_cvt_pk_u8_f32)
+//     and parked in LDS as u8 (i8 input) or u16 (i16 input);
+//   * the gate runs "transposed": each lane slides along its own run of kRun consecutive
+//     offsets, two runs packed in the halves of one VGPR so every min/max is one
+//     v_pk_min_u16 / v_pk_max_u16 for two offsets; running pair/quad maxima are shared between
+//     neighbouring offsets, so the preamble test costs ~5.5 VALU per offset;
+//   * survivors are kept as a per-lane 64-bit mask -> LDS bitmap -> ordered list (wave prefix
+//     sums), then decoded by 16-lane groups (one lane per frame byte) straight from the LDS
+//     magnitudes, with a 112-entry syndrome table for CRC and single-bit repair;
+//   * frames go to per-tile slots; a scan + gather pass puts them in ascending (channel,
+//     offset) order -- the order the reference's mpsc channel would deliver them in.
+#include "adsb_kernels.h"
+#include "adsb_synth.h"
+
+namespace adsbk {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// ---- small device helpers -------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b)
+{
+    u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b)
+{
+    u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+// VOP3P form with the accumulator in an SGPR: the VOP2 v_dot4c form hipcc picks for the builtin
+// needs a v_mov per call to preload the constant.
+__device__ __forceinline__ int dot4_sacc(uint32_t a, uint32_t b, int c)
+{
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+// CRC-24 syndrome table: kSyn[j] = x^(111-j) mod 0x1FFF409, j = 0..111 (bit j MSB-first of the
+// 112-bit frame).  XOR over the set bits of a frame is CRC24(data) ^ crc_field; for j < 88 it is
+// also the syndrome of a single error in data bit j (the 88 values are distinct and non-zero,
+// which is why the reference's ordered brute force, crc.rs:49-65, has at most one match).
+struct SynTable {
+    uint32_t v[112];
+};
+constexpr SynTable make_syn()
+{
+    SynTable t{};
+    uint32_t r = 1; // x^0
+    for (int e = 0; e < 112; ++e) {
+        t.v[111 - e] = r;
+        r <<= 1;
+        if (r & 0x1000000u) r ^= 0x1FFF409u;
+    }
+    return t;
+}
+__constant__ SynTable kSyn = make_syn();
+
+// ---- magnitude ------------------------------------------------------------------------------
+// floor(sqrt(n)) for n = I^2+Q^2 <= 32768 (i8 input), exact:
+// sqrt(n + 0.5) is at least 1.3e-3 away from every integer for n <= 32768, far more than the
+// 1-ulp error of v_sqrt_f32, so truncating it gives floor(sqrt(n)) -- the value the reference
+// gets from f64 sqrt + `as u32` (utils.rs:48).  n + 0.5 is formed without an int->float
+// convert: the dot product accumulates onto 0x4B000000 (2^23 as float bits), so the integer
+// result reinterpreted as float is 2^23 + n, and one subtraction of (2^23 - 0.5) is exact.
+template <int MAGMODE>
+__device__ __forceinline__ float mag_root_i8(uint32_t pair_dword, uint32_t mask)
+{
+    int n = dot4_sacc(pair_dword, pair_dword & mask, 0x4B000000);
+    float f = __builtin_bit_cast(float, n) - 8388607.5f;
+    float r = __builtin_amdgcn_sqrtf(f);
+    if (MAGMODE == 2) r -= 0.5f; // converter rounds to nearest: land in (k-0.5, k+0.5)
+    return r;
+}
+
+// 8 consecutive i8 IQ samples (16 bytes) -> 8 magnitudes packed as bytes in two dwords.
+template <int MAGMODE>
+__device__ __forceinline__ void mags8_i8(u32x4 v, uint32_t &lo, uint32_t &hi)
+{
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.x, 0x0000FFFFu), 0, 0u);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.x, 0xFFFF0000u), 1, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.y, 0x0000FFFFu), 2, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.y, 0xFFFF0000u), 3, lo);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.z, 0x0000FFFFu), 0, 0u);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.z, 0xFFFF0000u), 1, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.w, 0x0000FFFFu), 2, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.w, 0xFFFF0000u), 3, hi);
+}
+
+// floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): float estimate, then an exact integer
+// correction (the float path alone is off by one near perfect squares).
+__device__ __forceinline__ uint32_t mag_i16(uint32_t iq)
+{
+    int i = (int)(short)(iq & 0xFFFFu);
+    int q = (int)iq >> 16;
+    uint32_t n = (uint32_t)(i * i) + (uint32_t)(q * q);
+    uint32_t r = (uint32_t)__builtin_amdgcn_sqrtf((float)n);
+    r = r > 46341u ? 46341u : r;
+    r -= (r * r > n) ? 1u : 0u;            // estimate was one too high
+    r += ((r + 1u) * (r + 1u) <= n) ? 1u : 0u; // or one too low ((r+1)^2 <= 46342^2 < 2^32)
+    return r;
+}
+
+// ---- probe: how does v_cvt_pk_u8_f32 round here? --------------------------------------------
+__global__ void probe_cvt_kernel(uint32_t *out)
+{
+    if (threadIdx.x != 0) return;
+    float a = 0.75f, b = 2.5f, c = 180.9986f;
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+    uint32_t r0 = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0u);
+    r0 = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, r0);
+    r0 = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, r0);
+    out[0] = r0;
+    // MODE.fp_round: bits [1:0] = f32 rounding; 3 = toward zero
+    __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+    uint32_t r1 = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0u);
+    r1 = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, r1);
+    r1 = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, r1);
+    out[1] = r1;
+    __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
+    out[2] = 0xC0DEu;
+    out[3] = 0;
+}
+
+hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4])
+{
+    hipLaunchKernelGGL(probe_cvt_kernel, dim3(1), dim3(64), 0, s, dev_scratch4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(host_out, dev_scratch4, 16, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+}
+
+// ---- the fused tile kernel ------------------------------------------------------------------
+template <int ST> struct MagT;
+template <> struct MagT<ADSB_SAMPLE_I8> { typedef uint8_t type; };
+template <> struct MagT<ADSB_SAMPLE_I16> { typedef uint16_t type; };
+
+template <int ST> struct Lds {
+    typedef typename MagT<ST>::type mag_t;
+    static constexpr int kMagBytes = kMag * (int)sizeof(mag_t);
+    static constexpr int kOffCand = kMagBytes;                 // 1024 x u32 candidate bitmap
+    static constexpr int kOffList = kOffCand + kTile / 8;      // kListCap x u16
+    static constexpr int kOffSyn = kOffList + kListCap * 2;    // 112 x u32
+    static constexpr int kOffRes = kOffSyn + 112 * 4;          // 16 groups x 24 B
+    static constexpr int kOffMisc = kOffRes + 16 * 24;         // 16 x u32
+    static constexpr int kTotal = kOffMisc + 64;
+};
+
+// Packed pair for sample k of a lane's two runs: low half = run A, high half = run B.
+template <int ST>
+__device__ __forceinline__ uint32_t pair_at(const uint32_t *ra, const uint32_t *rb, int k)
+{
+    if (ST == ADSB_SAMPLE_I8) {
+        // bytes: [A.k, 0, B.k, 0]; selectors 0-3 pick from the 2nd operand, 4-7 from the 1st
+        const uint32_t sel = 0x0C000C00u | (uint32_t)(k & 3) | ((uint32_t)(4 + (k & 3)) << 16);
+        return __builtin_amdgcn_perm(rb[k >> 2], ra[k >> 2], sel);
+    } else {
+        const uint32_t sel = (k & 1) ? 0x07060302u : 0x05040100u;
+        return __builtin_amdgcn_perm(rb[k >> 1], ra[k >> 1], sel);
+    }
+}
+
+// Same value as pair_at with the two source operands exchanged (selectors adjusted): used on the
+// rarely taken DF17 path so that hipcc does not merge these with the main path's next-step pair
+// and grow a phi (extra exec juggling on every step).
+template <int ST>
+__device__ __forceinline__ uint32_t pair_at_cold(const uint32_t *ra, const uint32_t *rb, int k)
+{
+    if (ST == ADSB_SAMPLE_I8) {
+        const uint32_t sel = 0x0C000C00u | (uint32_t)(4 + (k & 3)) | ((uint32_t)(k & 3) << 16);
+        return __builtin_amdgcn_perm(ra[k >> 2], rb[k >> 2], sel);
+    } else {
+        const uint32_t sel = (k & 1) ? 0x03020706u : 0x01000504u;
+        return __builtin_amdgcn_perm(ra[k >> 1], rb[k >> 1], sel);
+    }
+}
+
+template <int ST, int MAGMODE>
+__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? 4 : 2)) void demod_tiles(DemodArgs p)
+{
+    typedef Lds<ST> L;
+    typedef typename L::mag_t mag_t;
+    constexpr int BPS = (ST == ADSB_SAMPLE_I8) ? 2 : 4; // bytes per IQ sample
+    constexpr int SPG = 16 / (int)sizeof(mag_t);         // magnitudes per 16-byte LDS granule
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
+    mag_t *mag = reinterpret_cast<mag_t *>(smem);
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + L::kOffCand);
+    uint16_t *list = reinterpret_cast<uint16_t *>(smem + L::kOffList);
+    uint32_t *syn = reinterpret_cast<uint32_t *>(smem + L::kOffSyn);
+    unsigned char *res = smem + L::kOffRes;
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = p.tile_first + blockIdx.x;        // global tile id
+    const uint32_t ch = tile / p.tiles_per_channel;
+    const uint32_t tch = tile - ch * p.tiles_per_channel;   // tile inside its channel
+    const uint64_t sample0 = (uint64_t)tch * kTile;          // first sample/offset of the tile
+    const uint64_t n_offsets = p.n_samples - kWindow;        // offsets 0..n_offsets-1 are valid
+    const uint32_t n_valid = (uint32_t)((n_offsets - sample0) < (uint64_t)kTile
+                                            ? (n_offsets - sample0) : (uint64_t)kTile);
+
+    if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
+
+    if (tid < 112) syn[tid] = kSyn.v[tid];
+    if (tid == 0) misc[8] = 0; // valid-frame counter
+
+    // ---- phase 1: raw IQ -> magnitudes in LDS -------------------------------------------------
+    {
+        const char *base = (const char *)p.iq + ((uint64_t)ch * p.channel_stride + sample0) * BPS;
+        uint64_t remain = (p.n_samples - sample0) * BPS; // bytes to the end of this channel
+        uint32_t nrec = remain > (uint64_t)(kMag * BPS) ? (uint32_t)(kMag * BPS) : (uint32_t)remain;
+        __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)nrec, 0x00020000);
+
+        if (ST == ADSB_SAMPLE_I8) {
+            constexpr int kIters = (kMag + kThreads * 8 - 1) / (kThreads * 8); // 17
+            u32x4 raw[kIters];
+#pragma unroll
+            for (int it = 0; it < kIters; ++it) {
+                uint32_t boff = (uint32_t)it * (kThreads * 16) + tid * 16;
+                raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, boff, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < kIters; ++it) {
+                uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
+                uint32_t lo, hi;
+                mags8_i8<MAGMODE>(raw[it], lo, hi);
+                if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+            }
+        } else {
+            constexpr int kIters = (kMag + kThreads * 4 - 1) / (kThreads * 4); // 33
+#pragma unroll 11
+            for (int it = 0; it < kIters; ++it) {
+                uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
+                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, s * 4, 0, 0);
+                uint32_t m0 = mag_i16(v.x), m1 = mag_i16(v.y), m2 = mag_i16(v.z), m3 = mag_i16(v.w);
+                if (s < (uint32_t)kMag)
+                    *reinterpret_cast<uint2 *>(mag + s) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 ------------------------
+    // Run A = offsets [tid*64, +64), run B = [(tid+256)*64, +64) of the tile.
+    uint32_t mA0 = 0, mA1 = 0, mB0 = 0, mB1 = 0; // survivors, bit o of word o>>5
+    {
+        constexpr int kGran = (kRun + 26 + SPG - 1) / SPG + 1; // granules a run may touch
+        const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * kRun);
+        const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + kThreads) * kRun);
+        uint32_t ra[kGran * 4], rb[kGran * 4];
+        constexpr int kAhead = 48 / SPG; // granules resident ahead of the current block
+#pragma unroll
+        for (int g = 0; g < kAhead; ++g) {
+            u32x4 a = ga[g], b = gb[g];
+            ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
+            rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
+        }
+
+        uint32_t N[kRun + 16], H2[kRun + 8], W2[kRun + 16], W4[kRun + 16];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) N[k] = pair_at<ST>(ra, rb, k);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
+#pragma unroll
+        for (int j = 3; j < 14; ++j) W2[j] = pkmax(N[j], N[j + 1]);
+#pragma unroll
+        for (int j = 3; j < 12; ++j) W4[j] = pkmax(W2[j], W2[j + 2]);
+
+#pragma unroll
+        for (int o = 0; o < kRun; ++o) {
+            if (o % SPG == 0) { // keep 48 samples resident ahead of the block that starts here
+                const int g = o / SPG + kAhead;
+                if (g * SPG < kRun + 26) {
+                    u32x4 a = ga[g], b = gb[g];
+                    ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
+                    rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
+                }
+            }
+            N[o + 15] = pair_at<ST>(ra, rb, o + 15);
+            W2[o + 14] = pkmax(N[o + 14], N[o + 15]);
+            W4[o + 12] = pkmax(W2[o + 12], W2[o + 14]);
+            const uint32_t w6 = pkmax(W4[o + 10], W2[o + 14]);   // lows 10..15
+            H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
+            const uint32_t hi = pkmin(H2[o], H2[o + 7]);          // highs 0,2,7,9
+            const uint32_t pp = pkmax(N[o + 1], N[o + 8]);        // lows 1,8
+            const uint32_t lo = pkmax(pkmax(pp, W4[o + 3]), w6);  // + lows 3..6
+            const bool pa = (uint16_t)hi >= (uint16_t)lo;
+            const bool pb = (hi >> 16) >= (lo >> 16);
+            if (pa | pb) {
+                // DF17 part of the gate (demod.rs:45-54), straight from the samples
+                const uint32_t n16 = pair_at_cold<ST>(ra, rb, o + 16), n17 = pair_at_cold<ST>(ra, rb, o + 17),
+                               n18 = pair_at_cold<ST>(ra, rb, o + 18), n19 = pair_at_cold<ST>(ra, rb, o + 19),
+                               n20 = pair_at_cold<ST>(ra, rb, o + 20), n21 = pair_at_cold<ST>(ra, rb, o + 21),
+                               n22 = pair_at_cold<ST>(ra, rb, o + 22), n23 = pair_at_cold<ST>(ra, rb, o + 23),
+                               n24 = pair_at_cold<ST>(ra, rb, o + 24), n25 = pair_at_cold<ST>(ra, rb, o + 25);
+                const uint32_t dh = pkmin(pkmin(pkmin(n16, n19), pkmin(n21, n23)), n24);
+                const uint32_t dl = pkmax(pkmax(pkmax(n17, n18), pkmax(n20, n22)), n25);
+                const bool da = (uint16_t)dh >= (uint16_t)dl;
+                const bool db = (dh >> 16) >= (dl >> 16);
+                const uint32_t bit = 1u << (o & 31);
+                if (o < 32) { mA0 |= (pa & da) ? bit : 0u; mB0 |= (pb & db) ? bit : 0u; }
+                else        { mA1 |= (pa & da) ? bit : 0u; mB1 |= (pb & db) ? bit : 0u; }
+            }
+        }
+        // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
+        const uint32_t sa = tid * kRun, sb = (tid + kThreads) * kRun;
+        const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
+        mA0 &= va >= 32 ? 0xFFFFFFFFu : ((1u << va) - 1u);
+        mA1 &= va >= 64 ? 0xFFFFFFFFu : (va > 32 ? ((1u << (va - 32)) - 1u) : 0u);
+        mB0 &= vb >= 32 ? 0xFFFFFFFFu : ((1u << vb) - 1u);
+        mB1 &= vb >= 64 ? 0xFFFFFFFFu : (vb > 32 ? ((1u << (vb - 32)) - 1u) : 0u);
+        *reinterpret_cast<uint2 *>(cand + 2 * tid) = make_uint2(mA0, mA1);
+        *reinterpret_cast<uint2 *>(cand + 2 * (tid + kThreads)) = make_uint2(mB0, mB1);
+    }
+    __syncthreads();
+
+    // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair ------------------
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    u32x4 cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
+    const uint32_t cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) +
+                         __builtin_popcount(cw.z) + __builtin_popcount(cw.w);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += t;
+    }
+    if (lane == 63) misc[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+        uint32_t t = misc[w];
+        wbase += (w < (int)wave) ? t : 0u;
+        total += t;
+    }
+    const uint32_t my_first = wbase + incl - cnt; // index of this thread's first candidate
+
+    if (tid == 0) {
+        uint32_t b = kNoBase;
+        if (total) {
+            const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+            b = (b64 + total <= (unsigned long long)p.cap_slots) ? (uint32_t)b64 : kNoBase;
+        }
+        misc[9] = b;
+    }
+    // (misc[9] becomes visible at the next barrier)
+
+    for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+        if (cnt) {
+            uint32_t idx = my_first;
+            const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t bits = words[k];
+                while (bits) {
+                    const uint32_t b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if (idx >= chunk && idx < chunk + kListCap)
+                        list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
+                    ++idx;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t base_slot = misc[9];
+        const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
+        const uint32_t g = tid >> 4, l = tid & 15;
+        for (uint32_t r = 0; r < ncl; r += 16) {
+            const uint32_t ci = r + g;
+            const bool have = ci < ncl; // uniform within the 16-lane group
+            const uint32_t off = have ? list[ci] : 0u;
+            // lane l slices frame byte l: magnitudes off+16+16l .. off+16+16l+15  (demod.rs:97-101)
+            const uint32_t lb = l < 14 ? l : 13;
+            uint32_t byte = 0;
+            {
+                const uint32_t pidx = off + 16 + 16 * lb; // magnitude index of the byte's first sample
+                if (ST == ADSB_SAMPLE_I8) {
+                    const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
+                    const uint32_t sh = pidx & 3;
+                    uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
+                    uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                     __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { // dword k holds pairs 2k and 2k+1
+                        byte |= ((w[k] & 0xFFu) > ((w[k] >> 8) & 0xFFu)) ? (0x80u >> (2 * k)) : 0u;
+                        byte |= (((w[k] >> 16) & 0xFFu) > (w[k] >> 24)) ? (0x40u >> (2 * k)) : 0u;
+                    }
+                } else {
+                    const mag_t *mp = mag + pidx;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        byte |= (mp[2 * k] > mp[2 * k + 1]) ? (0x80u >> k) : 0u;
+                }
+            }
+            // syndrome = XOR of table entries of the set bits, over the 14 bytes
+            uint32_t s = 0;
+            const uint32_t *sy = syn + 8 * lb;
+            if (l < 14) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s ^= (byte & (0x80u >> k)) ? sy[k] : 0u;
+            }
+            s ^= __shfl_xor(s, 1, 16);
+            s ^= __shfl_xor(s, 2, 16);
+            s ^= __shfl_xor(s, 4, 16);
+            s ^= __shfl_xor(s, 8, 16);
+            // single-bit repair: only the 88 data bits can match (crc.rs:49-65; flips in the CRC
+            // field leave the computed CRC unchanged, so they never match the received one)
+            int found = -1;
+            if (s != 0 && l < 11) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
+            }
+            const unsigned long long fm = __ballot(found >= 0);
+            const uint32_t gsh = (lane & 48u);
+            const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
+            const bool valid = have && (s == 0 || gbits != 0);
+            uint32_t status = 0xFFu, fixed = 0xFFu;
+            if (valid) {
+                status = (s == 0) ? 0u : 1u;
+                if (s != 0) {
+                    const uint32_t fl = __builtin_ctz(gbits);
+                    const int fk = __shfl(found, (int)fl, 16);
+                    fixed = 8 * fl + (uint32_t)fk;
+                    if (l == fl) byte ^= 0x80u >> fk;
+                }
+            }
+            // stage the 24-byte record, then 6 lanes store it as dwords
+            unsigned char *rec = res + g * 24;
+            if (l < 14) rec[8 + l] = (unsigned char)byte;
+            if (l == 14) rec[22] = (unsigned char)status;
+            if (l == 15) rec[23] = (unsigned char)fixed;
+            if (l == 0) {
+                const uint64_t o64 = sample0 + off;
+                reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
+                reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
+                if (valid) atomicAdd(&misc[8], 1u);
+            }
+            if (have && base_slot != kNoBase && l < 6) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);
+                dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
+            }
+        }
+        __syncthreads();
+    }
+    if (total == 0) __syncthreads(); // pair with the barrier inside the loop for misc[8]/[9]
+    if (tid == 0) {
+        Seg e;
+        e.base = misc[9];
+        e.cand = total;
+        e.valid = misc[8];
+        e.pad = 0;
+        p.seg[tile] = e;
+    }
+    if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
+}
+
+template <int ST>
+static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &a, uint32_t n)
+{
+    dim3 grid(n), block(kThreads);
+    switch (mag_mode) {
+    case 0: hipLaunchKernelGGL((demod_tiles<ST, 0>), grid, block, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((demod_tiles<ST, 1>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((demod_tiles<ST, 2>), grid, block, 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
+                        uint32_t n_tiles_launch)
+{
+    if (n_tiles_launch == 0) return hipSuccess;
+    if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, n_tiles_launch);
+    return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, n_tiles_launch);
+}
+
+// ---- ordering pass ---------------------------------------------------------------------------
+// scan: exclusive prefix of Seg::valid over all tiles (global tile order = channel-major, then
+// ascending offset) -> where each tile's frames go in the final list.
+__global__ __launch_bounds__(1024) void scan_tiles(CompactArgs a)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    int retry = 0;
+    for (uint32_t base = 0; base < a.n_tiles; base += 1024) {
+        const uint32_t t = base + tid;
+        uint32_t v = 0;
+        Seg e = {0, 0, 0, 0};
+        if (t < a.n_tiles) { e = a.seg[t]; v = e.valid; }
+        uint32_t incl = v; // <= 1024 tiles x 32768 frames: fits 32 bits
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t x = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += x;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wb = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { uint32_t x = wsum[w]; wb += (w < (int)wave) ? x : 0u; tot += x; }
+        const unsigned long long carry = carry_s;
+        const unsigned long long excl64 = carry + wb + incl - v;
+        const uint32_t excl = excl64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)excl64;
+        if (t < a.n_tiles) {
+            a.out_start[t] = excl; // saturated values are >= max_out, hence never gathered
+            if (v && e.base == kNoBase && excl < a.max_out) retry = 1;
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    retry = __syncthreads_or(retry);
+    if (tid == 0) {
+        const unsigned long long total = carry_s;
+        a.out_start[a.n_tiles] = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+        a.hdr->total_found = total;
+        a.hdr->n_out = total < a.max_out ? total : a.max_out;
+        a.hdr->flags = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
+        a.hdr->retry = retry ? 1u : 0u;
+        a.hdr->alloc = 0; // ready for the next launch
+    }
+    __syncthreads();
+    // frames per channel, clipped to what fits in max_out
+    for (uint32_t c = tid; c < a.n_channels; c += 1024) {
+        uint32_t b = a.out_start[c * a.tiles_per_channel];
+        uint32_t e = a.out_start[(c + 1) * a.tiles_per_channel];
+        b = b < a.max_out ? b : a.max_out;
+        e = e < a.max_out ? e : a.max_out;
+        a.chan_counts[c] = e - b;
+    }
+}
+
+// gather: one wave per tile copies its valid slots, in slot (= offset) order, to the final list.
+__global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t t = a.tile_first + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.tile_first + a.tile_count) return;
+    const Seg e = a.seg[t];
+    if (e.valid == 0 || e.base == kNoBase) return;
+    uint32_t pos = a.out_start[t];
+    if (pos >= a.max_out) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.slots + e.base);
+    for (uint32_t i0 = 0; i0 < e.cand; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0xFF0000u};
+        if (i < e.cand) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w[k] = src[(size_t)i * 6 + k];
+        }
+        const bool ok = (i < e.cand) && (((w[5] >> 16) & 0xFFu) != 0xFFu);
+        const unsigned long long m = __ballot(ok);
+        const uint32_t before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        const uint32_t dst = pos + before;
+        if (ok && dst < a.max_out) {
+            uint32_t *d = reinterpret_cast<uint32_t *>(a.out + dst);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[k] = w[k];
+        }
+        pos += (uint32_t)__builtin_popcountll(m);
+    }
+}
+
+hipError_t launch_scan(hipStream_t s, const CompactArgs &a)
+{
+    hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(hipStream_t s, const CompactArgs &a)
+{
+    if (a.tile_count == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_tiles, dim3((a.tile_count + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- test / measurement kernels -----------------------------------------------------------------
+template <int ST, int MAGMODE>
+__global__ void magnitudes_kernel(const void *iq, size_t n, uint16_t *out)
+{
+    if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (ST == ADSB_SAMPLE_I8) {
+        // 8 samples per thread-step through the same code path as the tile kernel
+        const size_t groups = (n + 7) / 8;
+        for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+            u32x4 v = {0, 0, 0, 0};
+            const uint16_t *src = reinterpret_cast<const uint16_t *>(iq) + g * 8;
+            uint16_t tmp[8];
+            for (int k = 0; k < 8; ++k) tmp[k] = (g * 8 + k < n) ? src[k] : (uint16_t)0;
+            v.x = tmp[0] | ((uint32_t)tmp[1] << 16);
+            v.y = tmp[2] | ((uint32_t)tmp[3] << 16);
+            v.z = tmp[4] | ((uint32_t)tmp[5] << 16);
+            v.w = tmp[6] | ((uint32_t)tmp[7] << 16);
+            uint32_t lo, hi;
+            mags8_i8<MAGMODE>(v, lo, hi);
+            for (int k = 0; k < 8; ++k)
+                if (g * 8 + k < n) out[g * 8 + k] = (uint16_t)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 0xFFu);
+        }
+    } else {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(iq);
+        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+            out[k] = (uint16_t)mag_i16(src[k]);
+    }
+    if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
+}
+
+hipError_t launch_magnitudes(hipStream_t s, int sample_type, int mag_mode, const void *iq, size_t n,
+                             uint16_t *out)
+{
+    if (n == 0) return hipSuccess;
+    dim3 grid(1024), block(256);
+    if (sample_type == ADSB_SAMPLE_I16) {
+        hipLaunchKernelGGL((magnitudes_kernel<ADSB_SAMPLE_I16, 0>), grid, block, 0, s, iq, n, out);
+    } else if (mag_mode == 0) {
+        hipLaunchKernelGGL((magnitudes_kernel<ADSB_SAMPLE_I8, 0>), grid, block, 0, s, iq, n, out);
+    } else if (mag_mode == 1) {
+        hipLaunchKernelGGL((magnitudes_kernel<ADSB_SAMPLE_I8, 1>), grid, block, 0, s, iq, n, out);
+    } else {
+        hipLaunchKernelGGL((magnitudes_kernel<ADSB_SAMPLE_I8, 2>), grid, block, 0, s, iq, n, out);
+    }
+    return hipGetLastError();
+}
+
+// Pure streaming read (16 B per lane, grid-stride): the box's own HBM read ceiling.
+__global__ __launch_bounds__(256) void read_only_kernel(const u32x4 *buf, size_t n16, uint32_t *sink)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        u32x4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n16; i += stride) {
+        u32x4 a = buf[i];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w;
+    }
+    if (acc == 0x9E3779B9u) *sink = acc; // practically never: keeps the loads alive
+}
+
+hipError_t launch_read_only(hipStream_t s, const void *buf, size_t bytes, uint32_t *sink)
+{
+    hipLaunchKernelGGL(read_only_kernel, dim3(256 * 8), dim3(256), 0, s,
+                       reinterpret_cast<const u32x4 *>(buf), bytes / 16, sink);
+    return hipGetLastError();
+}
+
+// Synthetic source: one thread per sample (untimed; clarity over speed).
+template <int ST>
+__global__ void synth_kernel(adsb_synth_cfg cfg, uint32_t channel, uint64_t first, size_t n, void *iq)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint64_t k = first + j;
+        const uint64_t slot = k / cfg.slot_len;
+        int vi, vq;
+        adsb_synth::noise_iq(cfg, channel, k, vi, vq);
+        // only samples inside a frame's 240-sample span need the slot's frame
+        adsb_synth::Slot s;
+        adsb_synth::slot_params(cfg, channel, slot, s);
+        if (s.present) {
+            const uint64_t start = slot * (uint64_t)cfg.slot_len + s.jitter;
+            if (k >= start && k < start + 240 && adsb_synth::pulse_at(s.sent, (uint32_t)(k - start))) {
+                vi += s.amp_i;
+                vq += s.amp_q;
+            }
+        }
+        if (ST == ADSB_SAMPLE_I8) {
+            reinterpret_cast<int8_t *>(iq)[2 * j] = (int8_t)adsb_synth::clip8(vi);
+            reinterpret_cast<int8_t *>(iq)[2 * j + 1] = (int8_t)adsb_synth::clip8(vq);
+        } else {
+            int wi = vi << cfg.amp_shift, wq = vq << cfg.amp_shift;
+            wi = wi < -32768 ? -32768 : (wi > 32767 ? 32767 : wi);
+            wq = wq < -32768 ? -32768 : (wq > 32767 ? 32767 : wq);
+            reinterpret_cast<int16_t *>(iq)[2 * j] = (int16_t)wi;
+            reinterpret_cast<int16_t *>(iq)[2 * j + 1] = (int16_t)wq;
+        }
+    }
+}
+
+hipError_t launch_synth(hipStream_t s, const adsb_synth_cfg &cfg, int sample_type, uint32_t channel,
+                        uint64_t first, size_t n, void *iq)
+{
+    if (n == 0) return hipSuccess;
+    dim3 grid(256 * 16), block(256);
+    if (sample_type == ADSB_SAMPLE_I8)
+        hipLaunchKernelGGL((synth_kernel<ADSB_SAMPLE_I8>), grid, block, 0, s, cfg, channel, first, n, iq);
+    else
+        hipLaunchKernelGGL((synth_kernel<ADSB_SAMPLE_I16>), grid, block, 0, s, cfg, channel, first, n, iq);
+    return hipGetLastError();
+}
+
+} // namespace adsbk

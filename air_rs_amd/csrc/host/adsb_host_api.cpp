@@ -1,0 +1,141 @@
+// adsb_host_api.cpp -- extern "C" wrappers (include/adsb_host.h) over the C++ host mirror.
+#include "../../../include/adsb_host.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "adsb_threads.hpp"
+
+using namespace air_rs_amd;
+
+static void fill_view(const AdsbPacket &p, adsb_packet_view *v)
+{
+    std::memset(v, 0, sizeof(*v));
+    std::memcpy(v->packet, p.bytes().data(), 14);
+    v->downlink_format = p.get_downlink_format();
+    v->capability = p.get_capability();
+    v->icao = p.icao;
+    v->msg_type = p.msg_type;
+    if (const AircraftID *id = std::get_if<AircraftID>(&p.msg)) {
+        v->msg_kind = ADSB_MSG_AIRCRAFT_ID;
+        std::strncpy(v->callsign, id->callsign.c_str(), 8);
+    } else if (const AircraftPosition *pos = std::get_if<AircraftPosition>(&p.msg)) {
+        v->msg_kind = ADSB_MSG_AIRCRAFT_POSITION;
+        v->surveillance_status = pos->surveillance_status;
+        v->nic_supplement = pos->nic_supplement;
+        v->altitude = pos->altitude;
+        v->cpr_time = pos->cpr_time;
+        v->cpr_odd = pos->cpr_format == CprFormat::Odd;
+        v->cpr_latitude = pos->cpr_latitude;
+        v->cpr_longitude = pos->cpr_longitude;
+    } else {
+        v->msg_kind = ADSB_MSG_UNKNOWN;
+        const UknownMsg &u = std::get<UknownMsg>(p.msg);
+        std::memcpy(v->raw_msg, u.raw_msg.data(), u.raw_msg.size() < 10 ? u.raw_msg.size() : 10);
+    }
+}
+
+extern "C" int adsb_packet_new(const uint8_t bytes[14], adsb_packet_view *out)
+{
+    if (!bytes || !out) return ADSB_E_ARG;
+    AdsbPacket p(std::vector<uint8_t>(bytes, bytes + 14));
+    fill_view(p, out);
+    return ADSB_OK;
+}
+
+extern "C" int adsb_packet_new_from_string(const char *hex, adsb_packet_view *out)
+{
+    if (!hex || !out || std::strlen(hex) != 28) return ADSB_E_ARG;
+    try {
+        AdsbPacket p = AdsbPacket::new_from_string(hex);
+        fill_view(p, out);
+    } catch (...) {
+        return ADSB_E_ARG;
+    }
+    return ADSB_OK;
+}
+
+extern "C" size_t adsb_packet_display(const uint8_t bytes[14], const char *time_text, char *dst, size_t cap)
+{
+    if (!bytes) return 0;
+    AdsbPacket p(std::vector<uint8_t>(bytes, bytes + 14));
+    std::string s = p.to_string(time_text ? time_text : "");
+    if (dst && cap > s.size()) std::memcpy(dst, s.c_str(), s.size() + 1);
+    return s.size();
+}
+
+template <typename T>
+static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_len, adsb_frame *frames,
+                        size_t max_frames, size_t *n_frames, uint64_t *n_buffers, char *text,
+                        size_t text_cap, size_t *text_len)
+{
+    const Complex<T> *src = static_cast<const Complex<T> *>(data);
+    std::vector<Complex<T>> all(src, src + n);
+
+    auto raw = channel<std::vector<Complex<T>>>(); // adsb.rs:131
+    auto msgs = channel<AdsbPacket>();             // adsb.rs:146
+    std::vector<adsb_frame> log;
+    Thread2Stats st;
+    std::string printed;
+
+    std::thread t1([tx = std::move(raw.first), d = std::move(all), chunk_len]() mutable {
+        playback_thread<T>(std::move(tx), std::move(d), chunk_len, false);
+    });
+    std::thread t2([&, rx = std::move(raw.second), tx = std::move(msgs.first)]() mutable {
+        st = process_sdr_data_thread<T>(ctx, std::move(rx), std::move(tx), &log, chunk_len);
+    });
+    std::thread t3([&, rx = std::move(msgs.second)]() mutable {
+        while (auto packet = rx.recv()) printed += "\n" + packet->to_string("") + "\n"; // adsb.rs:156-158
+    });
+    t1.join();
+    t2.join();
+    t3.join();
+
+    if (n_buffers) *n_buffers = st.buffers;
+    size_t nf = log.size() < max_frames ? log.size() : max_frames;
+    if (frames && nf) std::memcpy(frames, log.data(), nf * sizeof(adsb_frame));
+    if (n_frames) *n_frames = log.size();
+    if (text_len) *text_len = printed.size();
+    if (text && text_cap > printed.size()) std::memcpy(text, printed.c_str(), printed.size() + 1);
+    return st.last_error;
+}
+
+extern "C" int adsb_pipeline_playback(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples,
+                                      size_t chunk_len, adsb_frame *frames, size_t max_frames,
+                                      size_t *n_frames, uint64_t *n_buffers, char *text, size_t text_cap,
+                                      size_t *text_len)
+{
+    if (!ctx || !data || chunk_len == 0) return ADSB_E_ARG;
+    if (sample_type == ADSB_SAMPLE_I16)
+        return run_pipeline<int16_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
+                                     text, text_cap, text_len);
+    if (sample_type == ADSB_SAMPLE_I8)
+        return run_pipeline<int8_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
+                                    text, text_cap, text_len);
+    return ADSB_E_ARG;
+}
+
+extern "C" int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples)
+{
+    if (!path || !data || !n_samples) return ADSB_E_ARG;
+    IqBufI16 buf;
+    std::string err;
+    if (!load_data(path, buf, err)) return ADSB_E_ARG;
+    *n_samples = buf.size();
+    *data = static_cast<int16_t *>(std::malloc(buf.size() * 4 + 4));
+    if (!*data) return ADSB_E_NOMEM;
+    std::memcpy(*data, buf.data(), buf.size() * 4);
+    return ADSB_OK;
+}
+
+extern "C" int adsb_save_c16(const char *path, const int16_t *data, size_t n_samples)
+{
+    if (!path || (!data && n_samples)) return ADSB_E_ARG;
+    const Complex<int16_t> *src = reinterpret_cast<const Complex<int16_t> *>(data);
+    IqBufI16 buf(src, src + n_samples);
+    std::string err;
+    return save_data(buf, path, err) ? ADSB_OK : ADSB_E_ARG;
+}
+
+extern "C" void adsb_free(void *p) { std::free(p); }

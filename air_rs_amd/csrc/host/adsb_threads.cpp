@@ -1,0 +1,109 @@
+// adsb_threads.cpp -- see adsb_threads.hpp.
+#include "adsb_threads.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <thread>
+
+namespace air_rs_amd {
+
+bool load_data(const std::string &filename, IqBufI16 &out, std::string &err)
+{
+    std::ifstream f(filename, std::ios::binary | std::ios::ate);
+    if (!f) { err = "cannot open " + filename; return false; }
+    std::streamsize len = f.tellg();
+    if (len % 4 != 0) { err = "Invalid file length (not divisible by 4)"; return false; } // utils.rs:28-30
+    f.seekg(0);
+    std::vector<unsigned char> bytes((size_t)len);
+    if (len && !f.read(reinterpret_cast<char *>(bytes.data()), len)) { err = "short read"; return false; }
+    out.resize((size_t)len / 4);
+    for (size_t k = 0; k < out.size(); ++k) {
+        out[k].re = (int16_t)(bytes[4 * k] | (bytes[4 * k + 1] << 8));
+        out[k].im = (int16_t)(bytes[4 * k + 2] | (bytes[4 * k + 3] << 8));
+    }
+    return true;
+}
+
+bool save_data(const IqBufI16 &data, const std::string &filename, std::string &err)
+{
+    std::ofstream f(filename, std::ios::binary);
+    if (!f) { err = "cannot create " + filename; return false; }
+    std::vector<unsigned char> bytes(data.size() * 4);
+    for (size_t k = 0; k < data.size(); ++k) {
+        uint16_t re = (uint16_t)data[k].re, im = (uint16_t)data[k].im;
+        bytes[4 * k] = re & 0xFF; bytes[4 * k + 1] = re >> 8;
+        bytes[4 * k + 2] = im & 0xFF; bytes[4 * k + 3] = im >> 8;
+    }
+    f.write(reinterpret_cast<const char *>(bytes.data()), (std::streamsize)bytes.size());
+    return (bool)f;
+}
+
+template <typename T>
+void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>> data, size_t chunk_len, bool pace)
+{
+    // The reference computes `data.len()-20000` in usize: a shorter file underflows (panic in
+    // debug builds).  Here that case sends nothing.
+    size_t i = 0;
+    while (data.size() >= chunk_len && i < data.size() - chunk_len) {
+        std::vector<Complex<T>> buf(data.begin() + i, data.begin() + i + chunk_len);
+        i += chunk_len;
+        if (!tx.send(std::move(buf))) {
+            std::printf("Raw sdr receiver is dropped\n");
+            return;
+        }
+        if (pace) std::this_thread::sleep_for(std::chrono::duration<double>(1e4 / 2e6));
+    }
+    tx.drop();
+}
+
+template <typename T>
+Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex<T>>> rx,
+                                     Sender<AdsbPacket> tx, std::vector<adsb_frame> *frames_log,
+                                     size_t max_frames)
+{
+    Thread2Stats st;
+    // A buffer of n samples has n-240 offsets, so max_frames >= the largest buffer never truncates
+    // (the reference's channel is unbounded).
+    std::vector<adsb_frame> frames(max_frames);
+    uint64_t consumed = 0; // samples in earlier buffers, for the log's absolute offsets
+    while (auto buf = rx.recv()) {
+        size_t n_out = 0;
+        uint32_t flags = 0;
+        int rc = adsb_demod(ctx, buf->data(), buf->size(), frames.data(), frames.size(), &n_out, &flags);
+        if (rc == ADSB_OK && (flags & ADSB_FLAG_TRUNCATED)) st.truncated_buffers++;
+        if (rc != ADSB_OK) {
+            // ADSB_E_SHORT is where the reference panics (adsb.rs:98); any error ends the thread.
+            st.last_error = rc;
+            std::fprintf(stderr, "adsb_demod failed: %s\n", adsb_strerror(rc));
+            break;
+        }
+        st.buffers++;
+        bool closed = false;
+        for (size_t k = 0; k < n_out; ++k) {
+            if (frames_log) {
+                adsb_frame f = frames[k];
+                f.offset += consumed;
+                frames_log->push_back(f);
+            }
+            AdsbPacket packet(std::vector<uint8_t>(frames[k].bytes, frames[k].bytes + 14)); // adsb.rs:107
+            if (!tx.send(std::move(packet))) {
+                std::printf("Adsb msg receiver is dropped\n");
+                closed = true;
+                break;
+            }
+            st.frames++;
+        }
+        if (closed) return st;
+        consumed += buf->size();
+    }
+    tx.drop();
+    return st;
+}
+
+template void playback_thread<int16_t>(Sender<IqBufI16>, IqBufI16, size_t, bool);
+template void playback_thread<int8_t>(Sender<IqBufI8>, IqBufI8, size_t, bool);
+template Thread2Stats process_sdr_data_thread<int16_t>(adsb_ctx *, Receiver<IqBufI16>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t);
+template Thread2Stats process_sdr_data_thread<int8_t>(adsb_ctx *, Receiver<IqBufI8>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t);
+
+} // namespace air_rs_amd

@@ -1,0 +1,204 @@
+"""Python face of the demodulator context (one per GPU, one per calling thread).
+
+Mirrors the C ABI one to one; numpy arrays carry host buffers, integer device pointers (for
+example ``torch.Tensor.data_ptr()``) carry HBM-resident ones.  Frames come back as a numpy
+structured array with the adsb_frame layout.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+FRAME_DTYPE = np.dtype([("offset", "<u8"), ("bytes", "u1", (14,)), ("status", "u1"),
+                        ("fixed_bit", "u1")])
+assert FRAME_DTYPE.itemsize == C.sizeof(L.AdsbFrame) == 24
+
+WINDOW = 240  # 16 preamble + 112*2 samples (reference src/adsb.rs:98)
+
+
+def synth_default(**overrides):
+    cfg = L.AdsbSynthCfg()
+    L.load().adsb_synth_default(C.byref(cfg))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def synth_fill_host(cfg, sample_type, channel, first_sample, n_samples):
+    """Host copy of the synthetic stream: int8/int16 array of shape (n_samples, 2) = (I, Q)."""
+    dt = np.int8 if sample_type == L.ADSB_SAMPLE_I8 else np.int16
+    out = np.empty((n_samples, 2), dtype=dt)
+    L.check(L.load().adsb_synth_fill_host(C.byref(cfg), sample_type, channel, first_sample,
+                                          n_samples, out.ctypes.data), "adsb_synth_fill_host")
+    return out
+
+
+def synth_slot(cfg, channel, slot):
+    start = C.c_uint64()
+    clean = (C.c_uint8 * 14)()
+    sent = (C.c_uint8 * 14)()
+    kind = C.c_int()
+    r = L.load().adsb_synth_slot(C.byref(cfg), channel, slot, C.byref(start), C.byref(clean),
+                                 C.byref(sent), C.byref(kind))
+    if r < 0:
+        raise L.AdsbError(r, "adsb_synth_slot")
+    return bool(r), start.value, bytes(clean), bytes(sent), kind.value
+
+
+class AdsbDemod:
+    """adsb_ctx wrapper.  ``stream`` is a hipStream_t as int (e.g. torch's current stream)."""
+
+    def __init__(self, device=0, sample_type=L.ADSB_SAMPLE_I8, max_samples=1 << 20, max_out=1 << 16,
+                 max_channels=1, stream=None, host_staging=True):
+        self._lib = L.load()
+        cfg = L.AdsbCfg(L.ADSB_ABI_VERSION, device, sample_type, max_channels, max_samples, max_out,
+                        stream, 1 if host_staging else 0, 0)
+        h = C.c_void_p()
+        L.check(self._lib.adsb_create(C.byref(cfg), C.byref(h)), "adsb_create")
+        self._h = h
+        self.sample_type = sample_type
+        self.max_out = max_out
+        self.max_channels = max_channels
+        self._np_dtype = np.int8 if sample_type == L.ADSB_SAMPLE_I8 else np.int16
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.adsb_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self):
+        return self._lib.adsb_stream(self._h)
+
+    @property
+    def mag_mode(self):
+        return self._lib.adsb_debug_mag_mode(self._h)
+
+    # -- one received buffer (reference adsb.rs:95-116) -------------------------------------------
+    def demod(self, iq, max_out=None):
+        """iq: array of shape (n, 2) [I, Q] of the ctx sample dtype.  Returns (frames, flags)."""
+        iq = np.ascontiguousarray(iq, dtype=self._np_dtype)
+        n = iq.shape[0] if iq.ndim == 2 else iq.size // 2
+        cap = self.max_out if max_out is None else max_out
+        out = np.zeros(max(cap, 1), dtype=FRAME_DTYPE)
+        n_out = C.c_size_t()
+        flags = C.c_uint32()
+        L.check(self._lib.adsb_demod(self._h, iq.ctypes.data, n,
+                                     out.ctypes.data_as(C.POINTER(L.AdsbFrame)), cap, C.byref(n_out),
+                                     C.byref(flags)), "adsb_demod")
+        return out[:n_out.value].copy(), flags.value
+
+    # -- HBM-resident, asynchronous -----------------------------------------------------------------
+    def demod_device_async(self, dev_ptr, n_samples, n_channels=1, channel_stride=None):
+        stride = n_samples if channel_stride is None else channel_stride
+        L.check(self._lib.adsb_demod_device_async(self._h, dev_ptr, n_channels, n_samples, stride),
+                "adsb_demod_device_async")
+
+    def fetch(self, max_out=None, n_channels=1):
+        cap = self.max_out if max_out is None else max_out
+        out = np.zeros(max(cap, 1), dtype=FRAME_DTYPE)
+        n_out = C.c_size_t()
+        total = C.c_uint64()
+        flags = C.c_uint32()
+        counts = (C.c_uint64 * n_channels)()
+        L.check(self._lib.adsb_fetch(self._h, out.ctypes.data_as(C.POINTER(L.AdsbFrame)), cap,
+                                     C.byref(n_out), counts, C.byref(total), C.byref(flags)),
+                "adsb_fetch")
+        return out[:n_out.value].copy(), list(counts), total.value, flags.value
+
+    def fetch_counts(self):
+        n_out, total, flags = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        L.check(self._lib.adsb_fetch_counts(self._h, C.byref(n_out), C.byref(total), C.byref(flags)),
+                "adsb_fetch_counts")
+        return n_out.value, total.value, flags.value
+
+    def result_device(self):
+        frames, hdr = C.c_void_p(), C.c_void_p()
+        L.check(self._lib.adsb_result_device(self._h, C.byref(frames), C.byref(hdr)),
+                "adsb_result_device")
+        return frames.value, hdr.value
+
+    # -- measurement / test helpers -------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        L.check(self._lib.adsb_timing_enable(self._h, 1 if on else 0), "adsb_timing_enable")
+
+    def timing_read(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
+        L.check(self._lib.adsb_timing_read(self._h, C.byref(a), C.byref(b), C.byref(n)),
+                "adsb_timing_read")
+        return a.value, b.value, n.value
+
+    def time_read_ceiling(self, dev_ptr, nbytes, iters=10):
+        ms = C.c_double()
+        L.check(self._lib.adsb_time_read_ceiling(self._h, dev_ptr, nbytes, iters, C.byref(ms)),
+                "adsb_time_read_ceiling")
+        return ms.value
+
+    def magnitudes(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=self._np_dtype)
+        n = iq.shape[0]
+        out = np.empty(n, dtype=np.uint16)
+        L.check(self._lib.adsb_debug_magnitudes(self._h, iq.ctypes.data, n, out.ctypes.data),
+                "adsb_debug_magnitudes")
+        return out
+
+    def synth_fill_device(self, cfg, channel, first_sample, n_samples, dev_ptr):
+        L.check(self._lib.adsb_synth_fill_device(self._h, C.byref(cfg), channel, first_sample,
+                                                 n_samples, dev_ptr), "adsb_synth_fill_device")
+
+    # -- reference thread structure (playback + stream mode) ------------------------------------------
+    def pipeline_playback(self, data, chunk_len=20000, max_frames=1 << 20, want_text=True):
+        data = np.ascontiguousarray(data, dtype=self._np_dtype)
+        n = data.shape[0]
+        frames = np.zeros(max_frames, dtype=FRAME_DTYPE)
+        n_frames, n_buf, text_len = C.c_size_t(), C.c_uint64(), C.c_size_t()
+        cap = 1 << 26 if want_text else 0
+        text = C.create_string_buffer(cap) if want_text else None
+        L.check(self._lib.adsb_pipeline_playback(self._h, self.sample_type, data.ctypes.data, n,
+                                                 chunk_len,
+                                                 frames.ctypes.data_as(C.POINTER(L.AdsbFrame)),
+                                                 max_frames, C.byref(n_frames), C.byref(n_buf), text,
+                                                 cap, C.byref(text_len)), "adsb_pipeline_playback")
+        txt = text.value.decode() if want_text else None
+        return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value, txt
+
+
+def packet_new(frame_bytes):
+    """AdsbPacket::new (packet.rs:25-49) -> AdsbPacketView."""
+    b = (C.c_uint8 * 14)(*bytes(frame_bytes))
+    v = L.AdsbPacketView()
+    L.check(L.load().adsb_packet_new(C.byref(b), C.byref(v)), "adsb_packet_new")
+    return v
+
+
+def packet_new_from_string(hexstr):
+    v = L.AdsbPacketView()
+    L.check(L.load().adsb_packet_new_from_string(hexstr.encode(), C.byref(v)),
+            "adsb_packet_new_from_string")
+    return v
+
+
+def packet_display(frame_bytes, time_text=""):
+    b = (C.c_uint8 * 14)(*bytes(frame_bytes))
+    buf = C.create_string_buffer(2048)
+    n = L.load().adsb_packet_display(C.byref(b), time_text.encode(), buf, 2048)
+    return buf.value.decode()[:n]

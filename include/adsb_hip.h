@@ -1,0 +1,184 @@
+/*
+ * adsb_hip.h -- C ABI of the MI355X-native ADS-B demodulator (libadsb_hip.so).
+ *
+ * This is the drop-in boundary for air_rs's thread 2, `process_sdr_data_thread`
+ * (reference: src/adsb.rs:92-122).  The reference has no FFI of its own: thread 2 is a
+ * private Rust fn fed by `mpsc::Receiver<Vec<Complex<i16>>>` (adsb.rs:131) and feeding
+ * `mpsc::Sender<AdsbPacket>` (adsb.rs:146).  A maintainer keeps both channels and replaces the
+ * body of the `while let Ok(buf) = rx.recv()` loop (adsb.rs:95-116) with one call to
+ * adsb_demod() per received Vec, then builds `AdsbPacket::new(frame.bytes.to_vec())`
+ * (adsb.rs:107) for every returned frame, in the order returned.  INTEGRATION.md shows the
+ * Rust `extern "C"` block and the replacement loop.
+ *
+ * Everything here is plain C: opaque handle, pointers and sizes, POD structs, int return
+ * codes.  No exceptions cross the boundary.  A context is NOT thread-safe: one context per
+ * calling thread (the reference has exactly one consumer thread, adsb.rs:147) and one per GPU.
+ */
+#ifndef ADSB_HIP_H
+#define ADSB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADSB_ABI_VERSION 1
+
+/* ---- return codes ----------------------------------------------------------------------- */
+#define ADSB_OK 0
+/* n_samples < 240: the reference panics at adsb.rs:98 (`mags.len() - 240` underflows).
+ * The caller decides whether to mimic the panic. */
+#define ADSB_E_SHORT (-1)
+#define ADSB_E_ARG (-2)      /* NULL / misaligned / inconsistent argument                      */
+#define ADSB_E_CAPACITY (-3) /* n_samples or n_channels exceeds what the ctx was created for    */
+#define ADSB_E_NOMEM (-4)
+#define ADSB_E_NODEVICE (-5) /* no HIP device / HIP runtime failure at create                   */
+#define ADSB_E_STATE (-6)    /* fetch without a launch, etc.                                    */
+/* > 0 : a hipError_t from the HIP runtime */
+
+/* ---- flags returned by fetch/demod ------------------------------------------------------- */
+/* More than max_out frames exist; the first max_out (in offset order) were returned.
+ * The reference has no cap (unbounded mpsc); see SURVEY F8 for why a cap is needed. */
+#define ADSB_FLAG_TRUNCATED 0x1u
+
+/* ---- sample formats ---------------------------------------------------------------------- */
+/* ADSB_SAMPLE_I16 is the reference's `Complex<i16>` memory layout: interleaved {re, im},
+ * 4 bytes per sample (adsb.rs:131; file format utils.rs:22-43).
+ * ADSB_SAMPLE_I8 is interleaved {re, im} int8, 2 bytes per sample (RTL-SDR class radios,
+ * BASELINE.json's metric).  i8 results are by definition those of the reference path on the
+ * exactly widened i16 values. */
+#define ADSB_SAMPLE_I8 0
+#define ADSB_SAMPLE_I16 1
+
+/* One decoded Mode-S extended squitter.  24-byte POD, identical on host and device. */
+typedef struct adsb_frame {
+    uint64_t offset;    /* index i of the first preamble sample inside its buffer/channel        */
+    uint8_t  bytes[14]; /* what extract_packet returns (demod.rs:65-82): 11 data + 3 CRC bytes   */
+    uint8_t  status;    /* 0: CRC matched (demod.rs:81); 1: one data bit repaired (crc.rs:49-65) */
+    uint8_t  fixed_bit; /* status==1: repaired bit 0..87, MSB-first; otherwise 0xFF              */
+} adsb_frame;
+
+typedef struct adsb_cfg {
+    uint32_t abi_version;  /* ADSB_ABI_VERSION                                                    */
+    int32_t  device;       /* HIP device ordinal                                                  */
+    int32_t  sample_type;  /* ADSB_SAMPLE_I8 / ADSB_SAMPLE_I16                                    */
+    uint32_t max_channels; /* >= 1: how many independent buffers one launch may carry             */
+    uint64_t max_samples;  /* per channel; sizes the segment table (and the H2D staging buffer)   */
+    uint64_t max_out;      /* frames kept per launch, all channels together                       */
+    void    *stream;       /* hipStream_t to enqueue on; NULL: the ctx creates and owns one       */
+    uint32_t host_staging; /* 1: allocate a device staging buffer so adsb_demod() (host pointers)
+                              works; 0: device-resident entry points only                         */
+    uint32_t reserved;
+} adsb_cfg;
+
+typedef struct adsb_ctx adsb_ctx;
+
+/* Replaces nothing in the reference (it has no setup step); owns device buffers and stream. */
+int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx);
+void adsb_destroy(adsb_ctx *ctx);
+/* Static string for a return code of this library (HIP codes: hipGetErrorString). */
+const char *adsb_strerror(int code);
+
+/*
+ * adsb_demod -- one iteration of the reference loop (adsb.rs:95-116) for one received buffer.
+ *   iq        : host pointer, n_samples interleaved samples of cfg.sample_type
+ *   out       : host array of max_out frames, filled in ascending offset order
+ *   n_out     : number of frames written
+ *   flags     : ADSB_FLAG_*
+ * Returns ADSB_E_SHORT for n_samples < 240 (reference panics), ADSB_OK with *n_out = 0 for
+ * n_samples == 240 (reference: zero iterations).  Blocking.  Requires cfg.host_staging.
+ */
+int adsb_demod(adsb_ctx *ctx, const void *iq, size_t n_samples, adsb_frame *out, size_t max_out,
+               size_t *n_out, uint32_t *flags);
+
+/*
+ * Device-resident, asynchronous form (roofline configs, multi-channel batch).
+ *   iq_dev          : device pointer, 16-byte aligned
+ *   n_channels      : independent buffers; each is its own reference buffer (offsets
+ *                     0..n_samples-240 per channel; no window crosses a channel edge)
+ *   n_samples       : per channel
+ *   channel_stride  : samples between channel starts (>= n_samples, multiple of 8)
+ * Enqueues the kernels on the ctx stream and returns; results stay on the device until
+ * adsb_fetch()/adsb_result_device().
+ */
+int adsb_demod_device_async(adsb_ctx *ctx, const void *iq_dev, uint32_t n_channels,
+                            size_t n_samples, size_t channel_stride);
+
+/*
+ * Waits for the last launch and copies the frame list to the host.
+ *   out               : host array of max_out frames: channel 0's frames in ascending offset,
+ *                       then channel 1's, ...
+ *   n_out             : frames written (all channels)
+ *   per_channel_counts: optional array of n_channels uint64 (frames per channel in `out`)
+ *   total_found       : optional; number of frames that exist (> *n_out when TRUNCATED)
+ */
+int adsb_fetch(adsb_ctx *ctx, adsb_frame *out, size_t max_out, size_t *n_out,
+               uint64_t *per_channel_counts, uint64_t *total_found, uint32_t *flags);
+
+/* Waits for the last launch and returns only the counters (8+8+4 bytes of D2H). */
+int adsb_fetch_counts(adsb_ctx *ctx, uint64_t *n_out, uint64_t *total_found, uint32_t *flags);
+
+/*
+ * Zero-copy access for device-side consumers (e.g. an RCCL gather of the packet list):
+ *   frames_dev : adsb_frame[ ] in device memory, valid until the next launch on this ctx
+ *   header_dev : device pointer to { uint64 n_out; uint64 total_found; uint32 flags; ... }
+ * Does not synchronise; order against the ctx stream.
+ */
+int adsb_result_device(adsb_ctx *ctx, const adsb_frame **frames_dev, const void **header_dev);
+
+/* The stream the ctx enqueues on (hipStream_t as void*). */
+void *adsb_stream(adsb_ctx *ctx);
+
+/* ---- measurement / test helpers (bench.py, tests; not part of the reference's surface) ----- */
+/*
+ * With timing on, every adsb_demod_device_async() records HIP events on the ctx stream around
+ * the demodulation kernel and around the ordering pass (scan + gather).  adsb_timing_read()
+ * waits for the stream, returns the mean milliseconds per launch of each since the last read
+ * (at most the 512 most recent launches) and clears the log.
+ */
+int adsb_timing_enable(adsb_ctx *ctx, int on);
+int adsb_timing_read(adsb_ctx *ctx, double *demod_ms_mean, double *order_ms_mean,
+                     uint32_t *n_launches);
+/* Pure-read HBM ceiling on this device: streams `bytes` from `buf_dev` `iters` times with 16-byte
+ * loads and returns the mean milliseconds per pass. */
+int adsb_time_read_ceiling(adsb_ctx *ctx, const void *buf_dev, size_t bytes, int iters,
+                           double *ms_per_pass);
+/* floor(sqrt(I^2+Q^2)) of n host samples through the device magnitude code (utils.rs:46-52). */
+int adsb_debug_magnitudes(adsb_ctx *ctx, const void *iq_host, size_t n_samples,
+                          uint16_t *mags_host);
+/* How v_cvt_pk_u8_f32 was found to round on this device: 0 truncates, 1 truncates under
+ * MODE.fp_round = toward-zero, 2 rounds to nearest (kernel subtracts 0.5 first). */
+int adsb_debug_mag_mode(adsb_ctx *ctx);
+
+/* ---- deterministic synthetic IQ source --------------------------------------- */
+typedef struct adsb_synth_cfg {
+    uint64_t seed;
+    uint32_t slot_len;     /* one frame slot per slot_len samples (>= 256); 2000 = ~1000 msg/s */
+    uint32_t frame_pct;    /* 0..100: share of slots that carry a frame                        */
+    uint32_t pct_flip_data;/* of the frames: one flipped data bit  (must be repaired)          */
+    uint32_t pct_flip_crc; /* of the frames: one flipped CRC bit   (must be rejected)          */
+    uint32_t pct_flip_two; /* of the frames: two flipped data bits (must be rejected)          */
+    uint32_t noise_div;    /* noise = (sum of 4 hash bytes - 510) / noise_div; 18 -> sigma~8   */
+    uint32_t amp_shift;    /* i16 only: left shift applied to the i8-scale value (0..7)        */
+    uint32_t reserved;
+} adsb_synth_cfg;
+
+void adsb_synth_default(adsb_synth_cfg *cfg);
+/* Sample k of channel `channel` depends only on (cfg, channel, k): any slice of the stream can be
+ * generated independently (time-sharding across GPUs needs no input exchange). */
+int adsb_synth_fill_host(const adsb_synth_cfg *cfg, int sample_type, uint32_t channel,
+                         uint64_t first_sample, size_t n_samples, void *iq_host);
+int adsb_synth_fill_device(adsb_ctx *ctx, const adsb_synth_cfg *cfg, uint32_t channel,
+                           uint64_t first_sample, size_t n_samples, void *iq_dev);
+/* The frame (and what the demodulator must make of it) planted in slot `slot`:
+ * returns 1 if the slot carries a frame; start = first preamble sample (absolute),
+ * clean14 = the error-free frame, kind: 0 clean, 1 data-bit flip, 2 crc-bit flip, 3 two flips. */
+int adsb_synth_slot(const adsb_synth_cfg *cfg, uint32_t channel, uint64_t slot, uint64_t *start,
+                    uint8_t clean14[14], uint8_t sent14[14], int *kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADSB_HIP_H */

@@ -1,0 +1,71 @@
+/*
+ * adsb_host.h -- C ABI over the host-side mirror of air_rs's thread structure (libadsb_hip.so).
+ *
+ * The reference is a Rust binary with no Rust toolchain in this image, so the host side above
+ * include/adsb_hip.h is written in C++ (air_rs_amd/csrc/host/) with the reference's names:
+ * AdsbPacket (src/adsb/packet.rs:9-99), AircraftID / AircraftPosition / UknownMsg
+ * (src/adsb/msgs.rs), playback_thread (src/adsb.rs:75-89), process_sdr_data_thread
+ * (src/adsb.rs:92-122), load_data/save_data (src/utils.rs:6-43).  These C entry points exist so
+ * tests (ctypes) and other languages can drive that C++.
+ */
+#ifndef ADSB_HOST_H
+#define ADSB_HOST_H
+
+#include "adsb_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ADSB_MSG_AIRCRAFT_ID = 0, ADSB_MSG_AIRCRAFT_POSITION = 1, ADSB_MSG_UNKNOWN = 2 };
+
+/* Flat view of AdsbPacket (packet.rs:9-18) + its AdsbMsgType variant (msgs.rs:6-11). */
+typedef struct adsb_packet_view {
+    uint8_t  packet[14];
+    uint8_t  downlink_format;      /* packet.rs:26 */
+    uint8_t  capability;           /* packet.rs:27 (mask 5, as in the reference) */
+    uint32_t icao;                 /* packet.rs:28 */
+    uint8_t  msg_type;             /* packet.rs:29 */
+    int32_t  msg_kind;             /* ADSB_MSG_* */
+    char     callsign[9];          /* AircraftID, NUL terminated */
+    uint8_t  surveillance_status;  /* AircraftPosition ... */
+    uint8_t  nic_supplement;
+    int32_t  altitude;
+    uint8_t  cpr_time;
+    uint8_t  cpr_odd;
+    uint32_t cpr_latitude;
+    uint32_t cpr_longitude;
+    uint8_t  raw_msg[10];          /* UknownMsg: packet[4..14] */
+} adsb_packet_view;
+
+/* AdsbPacket::new (packet.rs:25-49). */
+int adsb_packet_new(const uint8_t bytes[14], adsb_packet_view *out);
+/* AdsbPacket::_new_from_string (packet.rs:56-68): 28 hex digits. */
+int adsb_packet_new_from_string(const char *hex, adsb_packet_view *out);
+/* `impl Display for AdsbPacket` (packet.rs:77-99).  time_text replaces the wall-clock value of
+ * the "Processed Time" line.  Returns the text length (without NUL); writes only if cap suffices. */
+size_t adsb_packet_display(const uint8_t bytes[14], const char *time_text, char *dst, size_t cap);
+
+/*
+ * launch_adsb in playback + stream mode (adsb.rs:126-173): thread 1 = playback_thread over
+ * `data`, thread 2 = process_sdr_data_thread on `ctx` (GPU), thread 3 collects what the stream
+ * printer would print ("\n{packet}\n" per packet, adsb.rs:157).
+ *   sample_type : layout of `data` (must match the ctx)
+ *   chunk_len   : samples per buffer (20000 in the reference); the tail is dropped as in adsb.rs:77
+ *   frames/max_frames/n_frames : the frames behind the packets, offsets absolute in `data`
+ *   text/text_cap/text_len     : optional stream-mode text, "Processed Time" lines blanked
+ * Returns ADSB_OK or the first error thread 2 met.
+ */
+int adsb_pipeline_playback(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples,
+                           size_t chunk_len, adsb_frame *frames, size_t max_frames, size_t *n_frames,
+                           uint64_t *n_buffers, char *text, size_t text_cap, size_t *text_len);
+
+/* utils.rs:22-43 / 6-20.  adsb_load_c16 allocates *data with malloc (free with adsb_free). */
+int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples);
+int adsb_save_c16(const char *path, const int16_t *data, size_t n_samples);
+void adsb_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
