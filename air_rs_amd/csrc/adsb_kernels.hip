@@ -43,13 +43,27 @@ __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b)
     u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
     return __builtin_bit_cast(uint32_t, r);
 }
-// VOP3P form with the accumulator in an SGPR: the VOP2 v_dot4c form hipcc picks for the builtin
-// needs a v_mov per call to preload the constant.
-__device__ __forceinline__ int dot4_sacc(uint32_t a, uint32_t b, int c)
+// Eight I^2+Q^2 sums (one 16-byte load = 8 samples) as VOP3P v_dot4_i32_i8 with the accumulator in
+// an SGPR.  Why asm: for the builtin hipcc picks the VOP2 v_dot4c form, which needs a v_mov per
+// call to preload the constant accumulator.  gfx950 needs 3 wait states between a DOT writing a
+// VGPR and a different VALU reading it; hipcc pads nothing for asm, so the block ends in s_nop 2
+// (the eight dots themselves may issue back to back).
+__device__ __forceinline__ void dot4x8_sacc(u32x4 v, int c, int n[8])
 {
-    int r;
-    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
+    const uint32_t a0 = v.x & 0xFFFFu, a1 = v.x & 0xFFFF0000u, a2 = v.y & 0xFFFFu, a3 = v.y & 0xFFFF0000u,
+                   a4 = v.z & 0xFFFFu, a5 = v.z & 0xFFFF0000u, a6 = v.w & 0xFFFFu, a7 = v.w & 0xFFFF0000u;
+    asm("v_dot4_i32_i8 %0, %8, %12, %20\n\t"
+        "v_dot4_i32_i8 %1, %8, %13, %20\n\t"
+        "v_dot4_i32_i8 %2, %9, %14, %20\n\t"
+        "v_dot4_i32_i8 %3, %9, %15, %20\n\t"
+        "v_dot4_i32_i8 %4, %10, %16, %20\n\t"
+        "v_dot4_i32_i8 %5, %10, %17, %20\n\t"
+        "v_dot4_i32_i8 %6, %11, %18, %20\n\t"
+        "v_dot4_i32_i8 %7, %11, %19, %20\n\t"
+        "s_nop 2"
+        : "=&v"(n[0]), "=&v"(n[1]), "=&v"(n[2]), "=&v"(n[3]), "=&v"(n[4]), "=&v"(n[5]), "=&v"(n[6]), "=&v"(n[7])
+        : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5),
+          "v"(a6), "v"(a7), "s"(c));
 }
 
 // CRC-24 syndrome table: kSyn[j] = x^(111-j) mod 0x1FFF409, j = 0..111 (bit j MSB-first of the
@@ -79,11 +93,9 @@ __constant__ SynTable kSyn = make_syn();
 // gets from f64 sqrt + `as u32` (utils.rs:48).  n + 0.5 is formed without an int->float
 // convert: the dot product accumulates onto 0x4B000000 (2^23 as float bits), so the integer
 // result reinterpreted as float is 2^23 + n, and one subtraction of (2^23 - 0.5) is exact.
-template <int MAGMODE>
-__device__ __forceinline__ float mag_root_i8(uint32_t pair_dword, uint32_t mask)
+template <int MAGMODE> __device__ __forceinline__ float mag_root_i8(int n_plus_2p23)
 {
-    int n = dot4_sacc(pair_dword, pair_dword & mask, 0x4B000000);
-    float f = __builtin_bit_cast(float, n) - 8388607.5f;
+    float f = __builtin_bit_cast(float, n_plus_2p23) - 8388607.5f;
     float r = __builtin_amdgcn_sqrtf(f);
     if (MAGMODE == 2) r -= 0.5f; // converter rounds to nearest: land in (k-0.5, k+0.5)
     return r;
@@ -93,14 +105,16 @@ __device__ __forceinline__ float mag_root_i8(uint32_t pair_dword, uint32_t mask)
 template <int MAGMODE>
 __device__ __forceinline__ void mags8_i8(u32x4 v, uint32_t &lo, uint32_t &hi)
 {
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.x, 0x0000FFFFu), 0, 0u);
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.x, 0xFFFF0000u), 1, lo);
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.y, 0x0000FFFFu), 2, lo);
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.y, 0xFFFF0000u), 3, lo);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.z, 0x0000FFFFu), 0, 0u);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.z, 0xFFFF0000u), 1, hi);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.w, 0x0000FFFFu), 2, hi);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(v.w, 0xFFFF0000u), 3, hi);
+    int n[8];
+    dot4x8_sacc(v, 0x4B000000, n);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[0]), 0, 0u);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[1]), 1, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[2]), 2, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[3]), 3, lo);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[4]), 0, 0u);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[5]), 1, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[6]), 2, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[7]), 3, hi);
 }
 
 // floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): float estimate, then an exact integer

@@ -1,0 +1,215 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Bit-exact: frames, offsets,
+status and repaired-bit index must all be identical (integer/byte work, no tolerance)."""
+import numpy as np
+import pytest
+
+import air_rs_amd as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    if len(got):
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (bad[:5], got[bad[:3]], want[bad[:3]])
+
+
+def _check(dem, oracle, iq, max_out=None):
+    frames, flags = dem.demod(iq, max_out)
+    rc, want, n = oracle.process_buffer(iq, max_out=dem.max_out if max_out is None else max_out)
+    assert rc == 0
+    cap = dem.max_out if max_out is None else max_out
+    assert bool(flags & A.ADSB_FLAG_TRUNCATED) == (n > cap)
+    _eq(frames, want)
+    return frames
+
+
+@pytest.fixture(scope="module")
+def dem8(gpu):
+    with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 18) as d:
+        yield d
+
+
+@pytest.fixture(scope="module")
+def dem16(gpu):
+    with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 21, max_out=1 << 18) as d:
+        yield d
+
+
+def test_magnitude_i8_exhaustive(dem8, oracle):
+    # every (I, Q) an i8 stream can carry: the device floor(sqrt) equals utils.rs:46-52
+    i, q = np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij")
+    iq = np.stack([i.ravel(), q.ravel()], axis=1).astype(np.int8)
+    got = dem8.magnitudes(iq)
+    want = oracle.get_magnitude(iq.astype(np.int16))
+    assert (got == want).all(), (dem8.mag_mode, np.nonzero(got != want)[0][:10])
+
+
+def test_magnitude_i16(dem16, oracle):
+    rng = np.random.default_rng(11)
+    iq = rng.integers(-32768, 32768, size=(1 << 20, 2)).astype(np.int16)
+    ks = np.arange(1, 32768, 7)
+    edge = np.concatenate([np.stack([ks, np.zeros_like(ks)], 1), np.stack([-ks, ks], 1),
+                           np.array([[-32768, -32768], [32767, 32767], [0, 0], [-32768, 0], [181, 181]])])
+    iq = np.concatenate([iq, edge.astype(np.int16)])
+    assert (dem16.magnitudes(iq) == oracle.get_magnitude(iq)).all()
+
+
+@pytest.mark.parametrize("n", [240, 241, 255, 271, 272, 1000, 20000, 32768 + 239, 32768 + 240, 32768 + 241,
+                               65536 + 240, 100003])
+def test_synthetic_sizes_i8(dem8, oracle, n):
+    cfg = A.synth_default(seed=100 + n, slot_len=600)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, n)
+    fr = _check(dem8, oracle, iq)
+    if n >= 20000:
+        assert len(fr) > 5
+
+
+def test_short_buffer(dem8):
+    with pytest.raises(A.AdsbError) as e:
+        dem8.demod(np.zeros((239, 2), dtype=np.int8))
+    assert e.value.code == A.ADSB_E_SHORT
+
+
+def test_constant_input_emits_every_offset(dem8, oracle):
+    # all-equal magnitudes pass the gate, slice to zeros, CRC(0) == 0
+    for val in (0, 127, -128):
+        iq = np.full((40000, 2), val, dtype=np.int8)
+        fr = _check(dem8, oracle, iq)
+        assert len(fr) == 40000 - 240
+
+
+def test_truncation_returns_first_frames(dem8, oracle):
+    iq = np.zeros((5000, 2), dtype=np.int8)
+    fr = _check(dem8, oracle, iq, max_out=100)
+    assert (fr["offset"] == np.arange(100)).all()
+
+
+def test_slot_store_overflow_is_replanned(gpu, oracle):
+    # far more survivors than max_out + one tile: the slot store overflows and the needed tiles are
+    # redone in batches; the first max_out frames must still come back, in order
+    with A.AdsbDemod(max_samples=400000, max_out=50000) as d:
+        iq = np.zeros((400000, 2), dtype=np.int8)
+        fr, flags = d.demod(iq)
+        assert flags & A.ADSB_FLAG_TRUNCATED
+        assert len(fr) == 50000 and (fr["offset"] == np.arange(50000)).all() and not fr["bytes"].any()
+        # and the ctx still works afterwards
+        cfg = A.synth_default(seed=5, slot_len=700)
+        x = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 150000)
+        _check(d, oracle, x)
+
+
+@pytest.mark.parametrize("noise_div", [18, 60, 200, 1020])
+def test_ties_and_noise_levels(dem8, oracle, noise_div):
+    # coarse noise -> many equal magnitudes: exercises `>=` in the gate and strict `>` in the slicer
+    cfg = A.synth_default(seed=noise_div, slot_len=900, noise_div=noise_div)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 300000)
+    _check(dem8, oracle, iq)
+
+
+def test_random_and_saturated(dem8, oracle):
+    rng = np.random.default_rng(7)
+    iq = rng.integers(-128, 128, size=(200000, 2)).astype(np.int8)
+    _check(dem8, oracle, iq)
+    iq = rng.choice(np.array([-128, -127, 126, 127], dtype=np.int8), size=(100000, 2))
+    _check(dem8, oracle, iq)
+    iq = rng.integers(-2, 3, size=(100000, 2)).astype(np.int8)
+    _check(dem8, oracle, iq)
+
+
+def test_error_mix(dem8, oracle):
+    # 40 % data-bit flips (repaired), 30 % crc-bit flips and 30 % double flips (rejected or, rarely,
+    # mis-repaired exactly as the reference would)
+    cfg = A.synth_default(seed=77, slot_len=500, pct_flip_data=40, pct_flip_crc=30, pct_flip_two=30)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 500000)
+    fr = _check(dem8, oracle, iq)
+    assert (fr["status"] == 1).sum() > 100
+    # every planted data-bit flip is repaired to the clean frame at the planted offset
+    by_off = {int(f["offset"]): f for f in fr}
+    seen = 0
+    for slot in range(500000 // 500 - 1):
+        present, start, clean, sent, kind = A.synth_slot(cfg, 0, slot)
+        if present and kind == 1 and start in by_off:
+            assert bytes(by_off[start]["bytes"]) == clean and by_off[start]["status"] == 1
+            seen += 1
+    assert seen > 100
+
+
+def test_large_buffer_i8(dem8, oracle):
+    cfg = A.synth_default(seed=2024)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 1 << 22)
+    fr = _check(dem8, oracle, iq)
+    assert len(fr) > 1500
+
+
+def test_device_generator_matches_host(dem8, gpu):
+    import torch
+    cfg = A.synth_default(seed=99)
+    n, first = 300001, 123457
+    t = torch.empty(n * 2, dtype=torch.int8, device="cuda")
+    dem8.synth_fill_device(cfg, 3, first, n, t.data_ptr())
+    torch.cuda.synchronize()
+    import ctypes
+    got = t.cpu().numpy().reshape(n, 2)
+    want = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 3, first, n)
+    assert (got == want).all()
+
+
+def test_multichannel_batch(gpu, oracle):
+    import torch
+    nch, n, stride = 5, 70001, 70008
+    with A.AdsbDemod(max_samples=n, max_out=1 << 16, max_channels=nch, host_staging=False) as d:
+        cfg = A.synth_default(seed=31, slot_len=800)
+        host = np.zeros((nch, stride, 2), dtype=np.int8)
+        for c in range(nch):
+            host[c, :n] = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, c, 0, n)
+        host[:, n:] = 77  # padding between channels must never be looked at
+        t = torch.from_numpy(host).cuda()
+        d.demod_device_async(t.data_ptr(), n, nch, stride)
+        frames, counts, total, flags = d.fetch(n_channels=nch)
+        pos = 0
+        for c in range(nch):
+            rc, want, cnt = oracle.process_buffer(host[c, :n])
+            assert counts[c] == cnt
+            _eq(frames[pos:pos + cnt], want)
+            pos += cnt
+        assert pos == len(frames) == total and flags == 0
+
+
+@pytest.mark.parametrize("n", [240, 241, 1000, 20000, 32768 + 241, 150001])
+def test_synthetic_sizes_i16(dem16, oracle, n):
+    cfg = A.synth_default(seed=400 + n, slot_len=600, amp_shift=5)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I16, 0, 0, n)
+    _check(dem16, oracle, iq)
+
+
+def test_i16_equals_widened_i8(dem8, dem16, oracle):
+    cfg = A.synth_default(seed=8)
+    iq8 = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 250000)
+    a, _ = dem8.demod(iq8)
+    b, _ = dem16.demod(iq8.astype(np.int16))
+    _eq(a, b)
+
+
+def test_i16_extremes(dem16, oracle):
+    rng = np.random.default_rng(5)
+    iq = rng.integers(-32768, 32768, size=(150000, 2)).astype(np.int16)
+    _check(dem16, oracle, iq)
+    iq = rng.choice(np.array([-32768, 32767, 0, 1], dtype=np.int16), size=(60000, 2))
+    _check(dem16, oracle, iq)
+    _check(dem16, oracle, np.full((3000, 2), -32768, dtype=np.int16))
+
+
+def test_playback_pipeline_matches_reference_chunking(dem16, oracle):
+    # config 1: 1 s of 2 MSPS CS16 through playback_thread -> process_sdr_data_thread -> stream text
+    cfg = A.synth_default(seed=1, amp_shift=4)
+    data = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I16, 0, 0, 2_000_000)
+    with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=20000, max_out=20000) as d:
+        frames, n_buf, text = d.pipeline_playback(data, chunk_len=20000)
+    chunks, want, n = oracle.playback(data, 20000)
+    assert n_buf == chunks == 99  # the 100th buffer is never sent (adsb.rs:77)
+    _eq(frames, want)
+    assert len(frames) > 800
+    expect_text = "".join("\n" + oracle.packet_display(bytes(f["bytes"]), "") + "\n" for f in want)
+    assert text == expect_text
