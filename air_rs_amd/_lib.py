@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libadsb_hip.so")
+# ADSB_HIP_LIB lets tuning experiments point at another build of the same library
+LIB_PATH = os.environ.get("ADSB_HIP_LIB") or os.path.join(_HERE, "lib", "libadsb_hip.so")
 
 ADSB_ABI_VERSION = 1
 ADSB_OK = 0

@@ -32,7 +32,11 @@ struct adsb_ctx {
     // device buffers
     void *staging = nullptr;        // host-fed input (cfg.host_staging)
     adsbk::Seg *seg = nullptr;      // [n_tiles_max]
-    uint32_t *out_start = nullptr;  // [n_tiles_max + 1]
+    uint32_t *out_start = nullptr;  // [n_tiles_max + 1]  (slot-overflow re-run path only)
+    uint32_t *grp = nullptr;        // two parities x (grp1[n_grp1] | grp2[n_grp2]) valid-frame counters
+    uint32_t n_grp1 = 0, n_grp2 = 0;
+    uint32_t parity = 0;            // which counter set the next launch uses
+    uint32_t n_cu = 256;
     uint64_t *chan_counts = nullptr;// [max_channels]
     adsb_frame *slots = nullptr;    // [cap_slots]
     adsb_frame *out = nullptr;      // [max_out]
@@ -102,6 +106,7 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     (void)hipFree(c->out);
     (void)hipFree(c->hdr);
     (void)hipFree(c->scratch);
+    (void)hipFree(c->grp);
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -127,9 +132,11 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     c->bps = cfg->sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
     uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples) * cfg->max_channels;
     if (tiles == 0) tiles = 1;
-    if (tiles > 0x7FFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
+    if (tiles * adsbk::kQuota + cfg->max_out + kTile > 0xFFFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
     c->n_tiles_max = (uint32_t)tiles;
     c->cap_slots = (uint32_t)(cfg->max_out + kTile);
+    c->n_grp1 = (c->n_tiles_max >> adsbk::kGrpShift) + 2;
+    c->n_grp2 = ((c->n_tiles_max >> (2 * adsbk::kGrpShift)) + 2) * adsbk::kGrp2Shards;
 
     int rc = ADSB_OK;
     auto fail = [&](int code) { rc = code; };
@@ -150,12 +157,19 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         if ((e = hipMalloc((void **)&c->seg, sizeof(adsbk::Seg) * (size_t)c->n_tiles_max)) != hipSuccess ||
             (e = hipMalloc((void **)&c->out_start, sizeof(uint32_t) * ((size_t)c->n_tiles_max + 1))) != hipSuccess ||
             (e = hipMalloc((void **)&c->chan_counts, sizeof(uint64_t) * cfg->max_channels)) != hipSuccess ||
-            (e = hipMalloc((void **)&c->slots, sizeof(adsb_frame) * (size_t)c->cap_slots)) != hipSuccess ||
+            (e = hipMalloc((void **)&c->slots, sizeof(adsb_frame) * ((size_t)c->n_tiles_max * adsbk::kQuota + c->cap_slots))) != hipSuccess ||
             (e = hipMalloc((void **)&c->out, sizeof(adsb_frame) * (size_t)cfg->max_out)) != hipSuccess ||
             (e = hipMalloc((void **)&c->hdr, sizeof(adsbk::Header))) != hipSuccess ||
-            (e = hipMalloc((void **)&c->scratch, 64)) != hipSuccess) {
+            (e = hipMalloc((void **)&c->scratch, 64)) != hipSuccess ||
+            (e = hipMalloc((void **)&c->grp, sizeof(uint32_t) * 2 * ((size_t)c->n_grp1 + c->n_grp2))) != hipSuccess) {
             fail(ADSB_E_NOMEM);
             break;
+        }
+        if (hipMemsetAsync(c->grp, 0, sizeof(uint32_t) * 2 * ((size_t)c->n_grp1 + c->n_grp2), c->stream) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+                c->n_cu = (uint32_t)prop.multiProcessorCount;
         }
         if (hipHostMalloc((void **)&c->hdr_host, sizeof(adsbk::Header), hipHostMallocDefault) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
         if (hipMemsetAsync(c->hdr, 0, sizeof(adsbk::Header), c->stream) != hipSuccess ||
@@ -178,7 +192,10 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
 extern "C" void *adsb_stream(adsb_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
 
-static adsbk::DemodArgs demod_args(adsb_ctx *c, uint32_t tile_first)
+static uint32_t *grp1_of(adsb_ctx *c, uint32_t parity) { return c->grp + (size_t)parity * (c->n_grp1 + c->n_grp2); }
+static uint32_t *grp2_of(adsb_ctx *c, uint32_t parity) { return grp1_of(c, parity) + c->n_grp1; }
+
+static adsbk::DemodArgs demod_args(adsb_ctx *c, uint32_t tile_first, uint32_t tile_count, bool count_groups)
 {
     adsbk::DemodArgs a{};
     a.iq = c->last_iq;
@@ -186,19 +203,30 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, uint32_t tile_first)
     a.channel_stride = c->last_stride;
     a.tiles_per_channel = c->last_tpc;
     a.tile_first = tile_first;
+    a.tile_count = tile_count;
+    a.count_groups = count_groups ? 1u : 0u;
     a.seg = c->seg;
     a.slots = c->slots;
+    a.pool_first = c->n_tiles_max * adsbk::kQuota;
     a.cap_slots = c->cap_slots;
     a.hdr = c->hdr;
+    a.grp1 = grp1_of(c, c->parity);
+    a.grp2 = grp2_of(c, c->parity);
     return a;
 }
 
-static adsbk::CompactArgs compact_args(adsb_ctx *c, uint32_t tile_first, uint32_t tile_count)
+static adsbk::CompactArgs compact_args(adsb_ctx *c, uint32_t tile_first, uint32_t tile_count, bool rerun)
 {
     adsbk::CompactArgs a{};
     a.seg = c->seg;
     a.slots = c->slots;
-    a.out_start = c->out_start;
+    a.out_start = rerun ? c->out_start : nullptr;
+    a.grp1 = grp1_of(c, c->parity);
+    a.grp2 = grp2_of(c, c->parity);
+    a.zero1 = rerun ? nullptr : grp1_of(c, c->parity ^ 1u);
+    a.zero2 = rerun ? nullptr : grp2_of(c, c->parity ^ 1u);
+    a.n_grp1 = c->n_grp1;
+    a.n_grp2 = c->n_grp2;
     a.chan_counts = c->chan_counts;
     a.out = c->out;
     a.n_tiles = c->last_tiles;
@@ -207,6 +235,7 @@ static adsbk::CompactArgs compact_args(adsb_ctx *c, uint32_t tile_first, uint32_
     a.max_out = (uint32_t)c->cfg.max_out;
     a.tile_first = tile_first;
     a.tile_count = tile_count;
+    a.write_header = rerun ? 0u : 1u;
     a.hdr = c->hdr;
     return a;
 }
@@ -240,11 +269,11 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
         ev = c->ev[c->ev_count % kTimingRing];
         HIPCHK(hipEventRecord(ev[0], c->stream));
     }
-    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, 0), c->last_tiles));
+    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode,
+                               demod_args(c, 0, c->last_tiles, true), c->n_cu));
     if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
-    adsbk::CompactArgs ca = compact_args(c, 0, c->last_tiles);
-    HIPCHK(adsbk::launch_scan(c->stream, ca));
-    HIPCHK(adsbk::launch_gather(c->stream, ca));
+    HIPCHK(adsbk::launch_gather(c->stream, compact_args(c, 0, c->last_tiles, false)));
+    c->parity ^= 1u; // the gather just cleared the other set for the next launch
     if (ev) {
         HIPCHK(hipEventRecord(ev[2], c->stream));
         c->ev_count++;
@@ -259,26 +288,39 @@ static int rerun_in_batches(adsb_ctx *c)
 {
     const uint32_t n = c->last_tiles;
     std::vector<adsbk::Seg> seg(n);
-    std::vector<uint32_t> start((size_t)n + 1);
     HIPCHK(hipMemcpyAsync(seg.data(), c->seg, sizeof(adsbk::Seg) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(start.data(), c->out_start, sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> start((size_t)n + 1);
+    uint64_t run = 0;
+    for (uint32_t t = 0; t <= n; ++t) {
+        start[t] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+        if (t < n) run += seg[t].valid;
+    }
+    HIPCHK(hipMemcpyAsync(c->out_start, start.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
     uint32_t limit = 0;
     while (limit < n && start[limit] < (uint32_t)c->cfg.max_out) ++limit;
+    c->parity ^= 1u; // point back at the counter set the first pass filled (read-only here)
     uint32_t t0 = 0;
-    while (t0 < limit) {
+    int rc = ADSB_OK;
+    while (t0 < limit && rc == ADSB_OK) {
         uint64_t used = 0;
         uint32_t t1 = t0;
-        while (t1 < limit && used + seg[t1].cand <= c->cap_slots) used += seg[t1++].cand;
-        if (t1 == t0) return ADSB_E_STATE; // a single tile never exceeds cap_slots (>= kTile)
-        HIPCHK(hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream));
-        HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, t0), t1 - t0));
-        HIPCHK(adsbk::launch_gather(c->stream, compact_args(c, t0, t1 - t0)));
+        auto pool_need = [&](uint32_t t) { return seg[t].cand > adsbk::kQuota ? (uint64_t)seg[t].cand : 0ull; };
+        while (t1 < limit && used + pool_need(t1) <= c->cap_slots) used += pool_need(t1++);
+        if (t1 == t0) { rc = ADSB_E_STATE; break; } // a single tile never exceeds cap_slots (>= kTile)
+        hipError_t e;
+        if ((e = hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(&c->hdr->next_tile, 0, sizeof(uint32_t), c->stream)) != hipSuccess ||
+            (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, t0, t1 - t0, false), c->n_cu)) != hipSuccess ||
+            (e = adsbk::launch_gather(c->stream, compact_args(c, t0, t1 - t0, true))) != hipSuccess)
+            rc = (int)e;
         t0 = t1;
     }
+    c->parity ^= 1u;
     HIPCHK(hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(&c->hdr->next_tile, 0, sizeof(uint32_t), c->stream));
     HIPCHK(hipMemsetAsync(&c->hdr->retry, 0, sizeof(uint32_t), c->stream));
-    return ADSB_OK;
+    return rc;
 }
 
 static int sync_header(adsb_ctx *c)

@@ -9,14 +9,26 @@
 namespace adsbk {
 
 // ---- tiling constants (see DESIGN.md "Data layout") ---------------------------------------
-constexpr int kTile = 32768;    // offsets owned by one workgroup
-constexpr int kThreads = 256;   // 4 waves; 4 workgroups per CU for i8 (LDS-bound)
-constexpr int kRun = 64;        // consecutive offsets one lane slides over, per packed half
+#ifndef ADSB_KRUN
+#define ADSB_KRUN 64
+#endif
+constexpr int kThreads = 256;   // 4 waves per workgroup
+constexpr int kRun = ADSB_KRUN; // consecutive offsets one lane slides over, per packed half (<= 64)
+constexpr int kTile = 2 * kThreads * kRun; // offsets owned by one workgroup (32768 at kRun 64)
 constexpr int kHalo = 256;      // >= 239 extra samples so PPM never leaves the tile; 16-aligned
 constexpr int kMag = kTile + kHalo;
-constexpr int kListCap = 512;   // candidate offsets staged per decode chunk
+constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
+constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path
 constexpr int kWindow = 240;    // 16 + 112*2  (reference src/adsb.rs:98)
 constexpr uint32_t kNoBase = 0xFFFFFFFFu;
+// Every tile owns kQuota frame slots at a fixed place (slot = tile * kQuota + i), so the normal
+// case needs no allocation at all; only a tile with more gate survivors than that draws from the
+// shared pool with one returning atomic.  (One atomic per tile on a single address measured as the
+// bottleneck: ~80 atomics/us per address vs 62 tiles/us.)
+constexpr uint32_t kQuota = 32;
+// Level-2 group counters are sharded 16 ways by the level-1 group index so that the ~1000 tiles in
+// flight at any time never pile onto one address.
+constexpr int kGrp2Shards = 16;
 
 // One entry per tile, written unconditionally by the demod kernel.
 struct Seg {
@@ -32,25 +44,38 @@ struct Header {
     uint64_t total_found;  // frames that exist
     uint32_t flags;        // ADSB_FLAG_*
     uint32_t retry;        // internal: a needed tile lost its slots (slot store overflow)
-    unsigned long long alloc; // slot allocator (reset by the scan kernel)
+    unsigned long long alloc; // slot allocator (reset by the gather kernel)
+    uint32_t next_tile;    // tile ticket dispenser of the persistent demod kernel (reset likewise)
+    uint32_t pad;
 };
+
+// Tiles are grouped 64 x 64 so that any tile's position in the final list is a sum of at most
+// 3 x 64 counters (no separate scan kernel): grp1[t >> 6], grp2[t >> 12].
+constexpr int kGrpShift = 6;
 
 struct DemodArgs {
     const void *iq;            // channel 0, sample 0
     uint64_t n_samples;        // per channel
     uint64_t channel_stride;   // samples
     uint32_t tiles_per_channel;
-    uint32_t tile_first;       // global tile id of blockIdx.x == 0
+    uint32_t tile_first;       // global tile id of ticket 0
+    uint32_t tile_count;       // tickets 0 .. tile_count-1
+    uint32_t count_groups;     // 1: add Seg::valid into grp1/grp2; 0: re-run of known tiles
     Seg *seg;
-    adsb_frame *slots;
-    uint32_t cap_slots;
+    adsb_frame *slots;         // [n_tiles_max * kQuota] fixed region, then the pool
+    uint32_t pool_first;       // index of the pool's first slot
+    uint32_t cap_slots;        // pool capacity
     Header *hdr;
+    uint32_t *grp1, *grp2;     // this launch's parity
 };
 
 struct CompactArgs {
     const Seg *seg;
     const adsb_frame *slots;
-    uint32_t *out_start;       // [n_tiles + 1] exclusive scan of Seg::valid
+    const uint32_t *out_start; // optional [n_tiles]: host-planned positions (re-run path)
+    const uint32_t *grp1, *grp2;
+    uint32_t *zero1, *zero2;   // the other parity, cleared for the next launch (may be null)
+    uint32_t n_grp1, n_grp2;
     uint64_t *chan_counts;     // [n_channels]
     adsb_frame *out;
     uint32_t n_tiles;
@@ -58,6 +83,7 @@ struct CompactArgs {
     uint32_t n_channels;
     uint32_t max_out;
     uint32_t tile_first, tile_count; // gather range
+    uint32_t write_header;
     Header *hdr;
 };
 
@@ -67,8 +93,7 @@ struct CompactArgs {
 hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]);
 
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
-                        uint32_t n_tiles_launch);
-hipError_t launch_scan(hipStream_t s, const CompactArgs &a);
+                        uint32_t n_compute_units);
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a);
 
 // test / measurement kernels

@@ -17,13 +17,15 @@
 //     and parked in LDS as u8 (i8 input) or u16 (i16 input);
 //   * the gate runs "transposed": each lane slides along its own run of kRun consecutive
 //     offsets, two runs packed in the halves of one VGPR so every min/max is one
-//     v_pk_min_u16 / v_pk_max_u16 for two offsets; running pair/quad maxima are shared between
-//     neighbouring offsets, so the preamble test costs ~5.5 VALU per offset;
+//     packed instruction for two offsets (3-input v_pk_maximum3_f16 / v_pk_minimum3_f16 where the
+//     values allow it); running maxima/minima are shared between neighbouring offsets, so the
+//     preamble test costs 4.5 VALU instructions per offset;
 //   * survivors are kept as a per-lane 64-bit mask -> LDS bitmap -> ordered list (wave prefix
 //     sums), then decoded by 16-lane groups (one lane per frame byte) straight from the LDS
 //     magnitudes, with a 112-entry syndrome table for CRC and single-bit repair;
-//   * frames go to per-tile slots; a scan + gather pass puts them in ascending (channel,
-//     offset) order -- the order the reference's mpsc channel would deliver them in.
+//   * frames go to per-tile slots; a gather pass (tile positions from two levels of group
+//     counters, no separate scan) puts them in ascending (channel, offset) order -- the order
+//     the reference's mpsc channel would deliver them in.
 #include "adsb_kernels.h"
 #include "adsb_synth.h"
 
@@ -43,6 +45,32 @@ __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b)
     u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
     return __builtin_bit_cast(uint32_t, r);
 }
+// Three-input packed max/min.  i8 input: magnitudes are <= 181, so a packed pair is two small
+// non-negative f16 bit patterns (denormals, whose numeric order is their integer order) and gfx950's
+// v_pk_maximum3_f16 / v_pk_minimum3_f16 reduce three of them in one instruction.  i16 input:
+// magnitudes reach 46340 (not an ordered f16 pattern), so two integer v_pk_max_u16 / v_pk_min_u16.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int ST> __device__ __forceinline__ uint32_t pkmax3(uint32_t a, uint32_t b, uint32_t c)
+{
+    if (ST == ADSB_SAMPLE_I8) {
+        f16x2 r = __builtin_elementwise_maximum(
+            __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+            __builtin_bit_cast(f16x2, c));
+        return __builtin_bit_cast(uint32_t, r);
+    }
+    return pkmax(pkmax(a, b), c);
+}
+template <int ST> __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c)
+{
+    if (ST == ADSB_SAMPLE_I8) {
+        f16x2 r = __builtin_elementwise_minimum(
+            __builtin_elementwise_minimum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+            __builtin_bit_cast(f16x2, c));
+        return __builtin_bit_cast(uint32_t, r);
+    }
+    return pkmin(pkmin(a, b), c);
+}
+
 // Eight I^2+Q^2 sums (one 16-byte load = 8 samples) as VOP3P v_dot4_i32_i8 with the accumulator in
 // an SGPR.  Why asm: for the builtin hipcc picks the VOP2 v_dot4c form, which needs a v_mov per
 // call to preload the constant accumulator.  gfx950 needs 3 wait states between a DOT writing a
@@ -171,10 +199,10 @@ template <> struct MagT<ADSB_SAMPLE_I16> { typedef uint16_t type; };
 template <int ST> struct Lds {
     typedef typename MagT<ST>::type mag_t;
     static constexpr int kMagBytes = kMag * (int)sizeof(mag_t);
-    static constexpr int kOffCand = kMagBytes;                 // 1024 x u32 candidate bitmap
-    static constexpr int kOffList = kOffCand + kTile / 8;      // kListCap x u16
+    static constexpr int kOffCand = kMagBytes;                 // 2 words per run: survivor bitmap
+    static constexpr int kOffList = kOffCand + 2 * kThreads * 8; // kListCap x u16
     static constexpr int kOffSyn = kOffList + kListCap * 2;    // 112 x u32
-    static constexpr int kOffRes = kOffSyn + 112 * 4;          // 16 groups x 24 B
+    static constexpr int kOffRes = kOffSyn + 112 * 4;          // 16 groups x 24 B record staging
     static constexpr int kOffMisc = kOffRes + 16 * 24;         // 16 x u32
     static constexpr int kTotal = kOffMisc + 64;
 };
@@ -208,8 +236,42 @@ __device__ __forceinline__ uint32_t pair_at_cold(const uint32_t *ra, const uint3
     }
 }
 
+// Where a tile sits: global tile id -> channel, first sample, number of valid offsets.
+struct TilePos {
+    uint32_t ch;
+    uint64_t sample0;
+    uint32_t n_valid;
+};
+__device__ __forceinline__ TilePos tile_pos(const DemodArgs &p, uint32_t tile)
+{
+    TilePos t;
+    t.ch = tile / p.tiles_per_channel;
+    const uint32_t tch = tile - t.ch * p.tiles_per_channel;
+    t.sample0 = (uint64_t)tch * kTile;
+    const uint64_t left = (p.n_samples - kWindow) - t.sample0; // offsets 0..n-241 exist (adsb.rs:98)
+    t.n_valid = left < (uint64_t)kTile ? (uint32_t)left : (uint32_t)kTile;
+    return t;
+}
+
+// Bounds-checked descriptor over one tile's samples (+halo): reads past the channel end return 0,
+// so ragged tails need no branches.  `tile` must be wave-uniform.
+template <int BPS>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, const TilePos &t)
+{
+    const char *base = (const char *)p.iq + ((uint64_t)t.ch * p.channel_stride + t.sample0) * BPS;
+    const uint64_t remain = (p.n_samples - t.sample0) * BPS; // bytes to the end of this channel
+    const uint32_t nrec = remain > (uint64_t)(kMag * BPS) ? (uint32_t)(kMag * BPS) : (uint32_t)remain;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)nrec, 0x00020000);
+}
+
+constexpr int kRawIters = (kMag + kThreads * 8 - 1) / (kThreads * 8); // 17 x 16 B per lane (i8)
+
+#ifndef ADSB_WAVES_PER_SIMD
+#define ADSB_WAVES_PER_SIMD (kRun >= 64 ? 4 : (kRun >= 48 ? 5 : 6))
+#endif
+
 template <int ST, int MAGMODE>
-__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? 4 : 2)) void demod_tiles(DemodArgs p)
+__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : 2)) void demod_tiles(DemodArgs p)
 {
     typedef Lds<ST> L;
     typedef typename L::mag_t mag_t;
@@ -225,275 +287,312 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? 4 : 2)) void demo
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = p.tile_first + blockIdx.x;        // global tile id
-    const uint32_t ch = tile / p.tiles_per_channel;
-    const uint32_t tch = tile - ch * p.tiles_per_channel;   // tile inside its channel
-    const uint64_t sample0 = (uint64_t)tch * kTile;          // first sample/offset of the tile
-    const uint64_t n_offsets = p.n_samples - kWindow;        // offsets 0..n_offsets-1 are valid
-    const uint32_t n_valid = (uint32_t)((n_offsets - sample0) < (uint64_t)kTile
-                                            ? (n_offsets - sample0) : (uint64_t)kTile);
+    const uint32_t lane = tid & 63, wave = tid >> 6;
 
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
 
     if (tid < 112) syn[tid] = kSyn.v[tid];
-    if (tid == 0) misc[8] = 0; // valid-frame counter
-
-    // ---- phase 1: raw IQ -> magnitudes in LDS -------------------------------------------------
+    // One tile per workgroup; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU
+    // and starts the next tile as soon as one retires, which staggers the phases of co-resident
+    // workgroups: while one waits for its samples the others keep the VALU busy.  (A persistent,
+    // register-prefetching variant was measured slower: it needs 168 VGPRs, i.e. 12 waves per CU,
+    // and this kernel is VALU-issue-bound, not latency-bound -- DESIGN.md "What was tried".)
     {
-        const char *base = (const char *)p.iq + ((uint64_t)ch * p.channel_stride + sample0) * BPS;
-        uint64_t remain = (p.n_samples - sample0) * BPS; // bytes to the end of this channel
-        uint32_t nrec = remain > (uint64_t)(kMag * BPS) ? (uint32_t)(kMag * BPS) : (uint32_t)remain;
-        __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)nrec, 0x00020000);
+        const uint32_t ticket = blockIdx.x;
+        const uint32_t tile = p.tile_first + ticket;
+        const TilePos tp = tile_pos(p, tile);
+        const uint64_t sample0 = tp.sample0;
+        const uint32_t n_valid = tp.n_valid;
+        if (ticket == 0 && tid == 0) p.hdr->retry = 0;
+        if (tid == 0) { misc[8] = 0; misc[12] = 0; } // valid-frame counter, survivor counter
 
-        if (ST == ADSB_SAMPLE_I8) {
-            constexpr int kIters = (kMag + kThreads * 8 - 1) / (kThreads * 8); // 17
-            u32x4 raw[kIters];
+        // ---- phase 1: raw IQ -> magnitudes in LDS ---------------------------------------------
+        {
+            __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<BPS>(p, tp);
+            if (ST == ADSB_SAMPLE_I8) {
+                u32x4 raw[kRawIters];
 #pragma unroll
-            for (int it = 0; it < kIters; ++it) {
-                uint32_t boff = (uint32_t)it * (kThreads * 16) + tid * 16;
-                raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, boff, 0, 0);
+                for (int it = 0; it < kRawIters; ++it)
+                    raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, 0);
+#pragma unroll
+                for (int it = 0; it < kRawIters; ++it) {
+                    uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
+                    uint32_t lo, hi;
+                    mags8_i8<MAGMODE>(raw[it], lo, hi);
+                    if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+                }
+            } else {
+                constexpr int kIters = (kMag + kThreads * 4 - 1) / (kThreads * 4); // 33
+#pragma unroll 11
+                for (int it = 0; it < kIters; ++it) {
+                    uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
+                    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, s * 4, 0, 0);
+                    uint32_t m0 = mag_i16(v.x), m1 = mag_i16(v.y), m2 = mag_i16(v.z), m3 = mag_i16(v.w);
+                    if (s < (uint32_t)kMag)
+                        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+                }
             }
+        }
+        __syncthreads();
+
+        // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
+        // Run A = offsets [tid*64, +64), run B = [(tid+256)*64, +64) of the tile.
+        {
+            uint32_t mA0 = 0, mA1 = 0, mB0 = 0, mB1 = 0; // survivors, bit o of word o>>5
+            constexpr int kGran = (kRun + 26 + SPG - 1) / SPG + 1; // granules a run may touch
+            const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * kRun);
+            const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + kThreads) * kRun);
+            uint32_t ra[kGran * 4], rb[kGran * 4];
+            constexpr int kAhead = 48 / SPG; // granules resident ahead of the current block
 #pragma unroll
-            for (int it = 0; it < kIters; ++it) {
-                uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
-                uint32_t lo, hi;
-                mags8_i8<MAGMODE>(raw[it], lo, hi);
-                if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+            for (int g = 0; g < kAhead; ++g) {
+                u32x4 a = ga[g], b = gb[g];
+                ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
+                rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
+            }
+
+            // Sliding state shared by neighbouring offsets (all indices are compile-time after
+            // unrolling): N[j] sample pair, H2[j] = min(N[j], N[j+2]), W3[j] = max(N[j..j+2]).
+            uint32_t N[kRun + 26], H2[kRun + 8], W3[kRun + 16];
+#pragma unroll
+            for (int k = 0; k < 25; ++k) N[k] = pair_at<ST>(ra, rb, k);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
+#pragma unroll
+            for (int j = 3; j < 13; ++j) W3[j] = pkmax3<ST>(N[j], N[j + 1], N[j + 2]);
+
+#pragma unroll
+            for (int o = 0; o < kRun; ++o) {
+                if (o % SPG == 0) { // keep 48 samples resident ahead of the block that starts here
+                    const int g = o / SPG + kAhead;
+                    if (g * SPG < kRun + 26) {
+                        u32x4 a = ga[g], b = gb[g];
+                        ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
+                        rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
+                    }
+                }
+                // pairs are unpacked 26 samples ahead so the (rare) DF17 check below finds its ten
+                // samples already in registers
+                N[o + 25] = pair_at<ST>(ra, rb, o + 25);
+                W3[o + 13] = pkmax3<ST>(N[o + 13], N[o + 14], N[o + 15]);
+                const uint32_t w6 = pkmax(W3[o + 10], W3[o + 13]);               // lows 10..15
+                const uint32_t la = pkmax3<ST>(W3[o + 3], N[o + 6], N[o + 1]);   // lows 3,4,5,6 and 1
+                const uint32_t lo = pkmax3<ST>(la, N[o + 8], w6);                 // + low 8
+                H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
+                const uint32_t hi = pkmin(H2[o], H2[o + 7]);                      // highs 0,2,7,9
+                const bool pa = (uint16_t)hi >= (uint16_t)lo;
+                const bool pb = (hi >> 16) >= (lo >> 16);
+                if (pa | pb) {
+                    // DF17 part of the gate (demod.rs:45-54)
+                    const uint32_t dh = pkmin3<ST>(pkmin3<ST>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
+                    const uint32_t dl = pkmax3<ST>(pkmax3<ST>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
+                    const bool da = (uint16_t)dh >= (uint16_t)dl;
+                    const bool db = (dh >> 16) >= (dl >> 16);
+                    const uint32_t bit = 1u << (o & 31);
+                    if (o < 32) { mA0 |= (pa & da) ? bit : 0u; mB0 |= (pb & db) ? bit : 0u; }
+                    else        { mA1 |= (pa & da) ? bit : 0u; mB1 |= (pb & db) ? bit : 0u; }
+                }
+            }
+            // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
+            const uint32_t sa = tid * kRun, sb = (tid + kThreads) * kRun;
+            const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
+            mA0 &= va >= 32 ? 0xFFFFFFFFu : ((1u << va) - 1u);
+            mA1 &= va >= 64 ? 0xFFFFFFFFu : (va > 32 ? ((1u << (va - 32)) - 1u) : 0u);
+            mB0 &= vb >= 32 ? 0xFFFFFFFFu : ((1u << vb) - 1u);
+            mB1 &= vb >= 64 ? 0xFFFFFFFFu : (vb > 32 ? ((1u << (vb - 32)) - 1u) : 0u);
+            *reinterpret_cast<uint2 *>(cand + 2 * tid) = make_uint2(mA0, mA1);
+            *reinterpret_cast<uint2 *>(cand + 2 * (tid + kThreads)) = make_uint2(mB0, mB1);
+            // Survivors are rare (a handful per tile): the few lanes that have any append their
+            // offsets, unordered, to the list; wave 0 ranks them afterwards.  The bitmap above is
+            // only read if there turn out to be more than kSparseCap.
+            if (mA0 | mA1 | mB0 | mB1) {
+                const uint32_t c = __builtin_popcount(mA0) + __builtin_popcount(mA1) +
+                                   __builtin_popcount(mB0) + __builtin_popcount(mB1);
+                uint32_t pos = atomicAdd(&misc[12], c);
+                const uint32_t words[4] = {mA0, mA1, mB0, mB1};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t bits = words[k];
+                    const uint32_t base = (k < 2 ? sa : sb) + (k & 1) * 32;
+                    while (bits) {
+                        const uint32_t b = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        if (pos < (uint32_t)kSparseCap) list[pos] = (uint16_t)(base + b);
+                        ++pos;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
+        uint32_t total = misc[12];
+        const bool dense = total > (uint32_t)kSparseCap;
+        u32x4 cw = {0, 0, 0, 0};
+        uint32_t cnt = 0, my_first = 0;
+        if (!dense) {
+            // rank sort by one wave: entry i goes to position #{j : list[j] < list[i]}
+            if (wave == 0) {
+                const uint32_t e = lane < total ? list[lane] : 0xFFFFu;
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < total; ++j) rank += (list[j] < e) ? 1u : 0u;
+                if (lane < total) list[rank] = (uint16_t)e;
             }
         } else {
-            constexpr int kIters = (kMag + kThreads * 4 - 1) / (kThreads * 4); // 33
-#pragma unroll 11
-            for (int it = 0; it < kIters; ++it) {
-                uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
-                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, s * 4, 0, 0);
-                uint32_t m0 = mag_i16(v.x), m1 = mag_i16(v.y), m2 = mag_i16(v.z), m3 = mag_i16(v.w);
-                if (s < (uint32_t)kMag)
-                    *reinterpret_cast<uint2 *>(mag + s) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+            // dense fallback: ordered compaction of the bitmap by workgroup-wide prefix sums
+            cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
+            cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) +
+                  __builtin_popcount(cw.w);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += t;
             }
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 ------------------------
-    // Run A = offsets [tid*64, +64), run B = [(tid+256)*64, +64) of the tile.
-    uint32_t mA0 = 0, mA1 = 0, mB0 = 0, mB1 = 0; // survivors, bit o of word o>>5
-    {
-        constexpr int kGran = (kRun + 26 + SPG - 1) / SPG + 1; // granules a run may touch
-        const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * kRun);
-        const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + kThreads) * kRun);
-        uint32_t ra[kGran * 4], rb[kGran * 4];
-        constexpr int kAhead = 48 / SPG; // granules resident ahead of the current block
+            if (lane == 63) misc[wave] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            total = 0;
 #pragma unroll
-        for (int g = 0; g < kAhead; ++g) {
-            u32x4 a = ga[g], b = gb[g];
-            ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
-            rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
-        }
-
-        uint32_t N[kRun + 16], H2[kRun + 8], W2[kRun + 16], W4[kRun + 16];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) N[k] = pair_at<ST>(ra, rb, k);
-#pragma unroll
-        for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
-#pragma unroll
-        for (int j = 3; j < 14; ++j) W2[j] = pkmax(N[j], N[j + 1]);
-#pragma unroll
-        for (int j = 3; j < 12; ++j) W4[j] = pkmax(W2[j], W2[j + 2]);
-
-#pragma unroll
-        for (int o = 0; o < kRun; ++o) {
-            if (o % SPG == 0) { // keep 48 samples resident ahead of the block that starts here
-                const int g = o / SPG + kAhead;
-                if (g * SPG < kRun + 26) {
-                    u32x4 a = ga[g], b = gb[g];
-                    ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
-                    rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
-                }
+            for (int w = 0; w < kThreads / 64; ++w) {
+                uint32_t t = misc[w];
+                wbase += (w < (int)wave) ? t : 0u;
+                total += t;
             }
-            N[o + 15] = pair_at<ST>(ra, rb, o + 15);
-            W2[o + 14] = pkmax(N[o + 14], N[o + 15]);
-            W4[o + 12] = pkmax(W2[o + 12], W2[o + 14]);
-            const uint32_t w6 = pkmax(W4[o + 10], W2[o + 14]);   // lows 10..15
-            H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
-            const uint32_t hi = pkmin(H2[o], H2[o + 7]);          // highs 0,2,7,9
-            const uint32_t pp = pkmax(N[o + 1], N[o + 8]);        // lows 1,8
-            const uint32_t lo = pkmax(pkmax(pp, W4[o + 3]), w6);  // + lows 3..6
-            const bool pa = (uint16_t)hi >= (uint16_t)lo;
-            const bool pb = (hi >> 16) >= (lo >> 16);
-            if (pa | pb) {
-                // DF17 part of the gate (demod.rs:45-54), straight from the samples
-                const uint32_t n16 = pair_at_cold<ST>(ra, rb, o + 16), n17 = pair_at_cold<ST>(ra, rb, o + 17),
-                               n18 = pair_at_cold<ST>(ra, rb, o + 18), n19 = pair_at_cold<ST>(ra, rb, o + 19),
-                               n20 = pair_at_cold<ST>(ra, rb, o + 20), n21 = pair_at_cold<ST>(ra, rb, o + 21),
-                               n22 = pair_at_cold<ST>(ra, rb, o + 22), n23 = pair_at_cold<ST>(ra, rb, o + 23),
-                               n24 = pair_at_cold<ST>(ra, rb, o + 24), n25 = pair_at_cold<ST>(ra, rb, o + 25);
-                const uint32_t dh = pkmin(pkmin(pkmin(n16, n19), pkmin(n21, n23)), n24);
-                const uint32_t dl = pkmax(pkmax(pkmax(n17, n18), pkmax(n20, n22)), n25);
-                const bool da = (uint16_t)dh >= (uint16_t)dl;
-                const bool db = (dh >> 16) >= (dl >> 16);
-                const uint32_t bit = 1u << (o & 31);
-                if (o < 32) { mA0 |= (pa & da) ? bit : 0u; mB0 |= (pb & db) ? bit : 0u; }
-                else        { mA1 |= (pa & da) ? bit : 0u; mB1 |= (pb & db) ? bit : 0u; }
+            my_first = wbase + incl - cnt; // index of this thread's first candidate
+        }
+
+        // Frame slots: the tile's own fixed region when the survivors fit (no atomics), otherwise
+        // one allocation from the shared pool.
+        if (tid == 0) {
+            uint32_t b = tile * kQuota;
+            if (total > kQuota) {
+                const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+                b = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
             }
+            misc[9] = b;
         }
-        // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
-        const uint32_t sa = tid * kRun, sb = (tid + kThreads) * kRun;
-        const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
-        mA0 &= va >= 32 ? 0xFFFFFFFFu : ((1u << va) - 1u);
-        mA1 &= va >= 64 ? 0xFFFFFFFFu : (va > 32 ? ((1u << (va - 32)) - 1u) : 0u);
-        mB0 &= vb >= 32 ? 0xFFFFFFFFu : ((1u << vb) - 1u);
-        mB1 &= vb >= 64 ? 0xFFFFFFFFu : (vb > 32 ? ((1u << (vb - 32)) - 1u) : 0u);
-        *reinterpret_cast<uint2 *>(cand + 2 * tid) = make_uint2(mA0, mA1);
-        *reinterpret_cast<uint2 *>(cand + 2 * (tid + kThreads)) = make_uint2(mB0, mB1);
-    }
-    __syncthreads();
+        // (misc[9] becomes visible at the next barrier)
 
-    // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair ------------------
-    const uint32_t lane = tid & 63, wave = tid >> 6;
-    u32x4 cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
-    const uint32_t cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) +
-                         __builtin_popcount(cw.z) + __builtin_popcount(cw.w);
-    uint32_t incl = cnt;
+        for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+            if (dense && cnt) {
+                uint32_t idx = my_first;
+                const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(incl, d, 64);
-        if ((int)lane >= d) incl += t;
-    }
-    if (lane == 63) misc[wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) {
-        uint32_t t = misc[w];
-        wbase += (w < (int)wave) ? t : 0u;
-        total += t;
-    }
-    const uint32_t my_first = wbase + incl - cnt; // index of this thread's first candidate
-
-    if (tid == 0) {
-        uint32_t b = kNoBase;
-        if (total) {
-            const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
-            b = (b64 + total <= (unsigned long long)p.cap_slots) ? (uint32_t)b64 : kNoBase;
-        }
-        misc[9] = b;
-    }
-    // (misc[9] becomes visible at the next barrier)
-
-    for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
-        if (cnt) {
-            uint32_t idx = my_first;
-            const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t bits = words[k];
-                while (bits) {
-                    const uint32_t b = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    if (idx >= chunk && idx < chunk + kListCap)
-                        list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
-                    ++idx;
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t base_slot = misc[9];
-        const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
-        const uint32_t g = tid >> 4, l = tid & 15;
-        for (uint32_t r = 0; r < ncl; r += 16) {
-            const uint32_t ci = r + g;
-            const bool have = ci < ncl; // uniform within the 16-lane group
-            const uint32_t off = have ? list[ci] : 0u;
-            // lane l slices frame byte l: magnitudes off+16+16l .. off+16+16l+15  (demod.rs:97-101)
-            const uint32_t lb = l < 14 ? l : 13;
-            uint32_t byte = 0;
-            {
-                const uint32_t pidx = off + 16 + 16 * lb; // magnitude index of the byte's first sample
-                if (ST == ADSB_SAMPLE_I8) {
-                    const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
-                    const uint32_t sh = pidx & 3;
-                    uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
-                    uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                                     __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { // dword k holds pairs 2k and 2k+1
-                        byte |= ((w[k] & 0xFFu) > ((w[k] >> 8) & 0xFFu)) ? (0x80u >> (2 * k)) : 0u;
-                        byte |= (((w[k] >> 16) & 0xFFu) > (w[k] >> 24)) ? (0x40u >> (2 * k)) : 0u;
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t bits = words[k];
+                    while (bits) {
+                        const uint32_t b = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        if (idx >= chunk && idx < chunk + kListCap)
+                            list[idx - chunk] = (uint16_t)(((4 * tid + k) >> 1) * kRun + ((4 * tid + k) & 1) * 32 + b);
+                        ++idx;
                     }
-                } else {
-                    const mag_t *mp = mag + pidx;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        byte |= (mp[2 * k] > mp[2 * k + 1]) ? (0x80u >> k) : 0u;
                 }
             }
-            // syndrome = XOR of table entries of the set bits, over the 14 bytes
-            uint32_t s = 0;
-            const uint32_t *sy = syn + 8 * lb;
-            if (l < 14) {
+            __syncthreads();
+            const uint32_t base_slot = misc[9];
+            const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
+            const uint32_t g = tid >> 4, l = tid & 15;
+            for (uint32_t r = 0; r < ncl; r += 16) {
+                if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a candidate
+                const uint32_t ci = r + g;
+                const bool have = ci < ncl; // uniform within the 16-lane group
+                const uint32_t off = have ? list[ci] : 0u;
+                // lane l slices frame byte l: magnitudes off+16+16l .. off+16+16l+15  (demod.rs:97-101)
+                const uint32_t lb = l < 14 ? l : 13;
+                uint32_t byte = 0;
+                {
+                    const uint32_t pidx = off + 16 + 16 * lb; // magnitude index of the byte's first sample
+                    if (ST == ADSB_SAMPLE_I8) {
+                        const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
+                        const uint32_t sh = pidx & 3;
+                        uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
+                        uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s ^= (byte & (0x80u >> k)) ? sy[k] : 0u;
-            }
-            s ^= __shfl_xor(s, 1, 16);
-            s ^= __shfl_xor(s, 2, 16);
-            s ^= __shfl_xor(s, 4, 16);
-            s ^= __shfl_xor(s, 8, 16);
-            // single-bit repair: only the 88 data bits can match (crc.rs:49-65; flips in the CRC
-            // field leave the computed CRC unchanged, so they never match the received one)
-            int found = -1;
-            if (s != 0 && l < 11) {
+                        for (int k = 0; k < 4; ++k) { // dword k holds pairs 2k and 2k+1
+                            byte |= ((w[k] & 0xFFu) > ((w[k] >> 8) & 0xFFu)) ? (0x80u >> (2 * k)) : 0u;
+                            byte |= (((w[k] >> 16) & 0xFFu) > (w[k] >> 24)) ? (0x40u >> (2 * k)) : 0u;
+                        }
+                    } else {
+                        const mag_t *mp = mag + pidx;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
-            }
-            const unsigned long long fm = __ballot(found >= 0);
-            const uint32_t gsh = (lane & 48u);
-            const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
-            const bool valid = have && (s == 0 || gbits != 0);
-            uint32_t status = 0xFFu, fixed = 0xFFu;
-            if (valid) {
-                status = (s == 0) ? 0u : 1u;
-                if (s != 0) {
-                    const uint32_t fl = __builtin_ctz(gbits);
-                    const int fk = __shfl(found, (int)fl, 16);
-                    fixed = 8 * fl + (uint32_t)fk;
-                    if (l == fl) byte ^= 0x80u >> fk;
+                        for (int k = 0; k < 8; ++k)
+                            byte |= (mp[2 * k] > mp[2 * k + 1]) ? (0x80u >> k) : 0u;
+                    }
+                }
+                // syndrome = XOR of table entries of the set bits, over the 14 bytes
+                uint32_t s = 0;
+                const uint32_t *sy = syn + 8 * lb;
+                if (l < 14) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s ^= (byte & (0x80u >> k)) ? sy[k] : 0u;
+                }
+                s ^= __shfl_xor(s, 1, 16);
+                s ^= __shfl_xor(s, 2, 16);
+                s ^= __shfl_xor(s, 4, 16);
+                s ^= __shfl_xor(s, 8, 16);
+                // single-bit repair: only the 88 data bits can match (crc.rs:49-65; flips in the CRC
+                // field leave the computed CRC unchanged, so they never match the received one)
+                int found = -1;
+                if (s != 0 && l < 11) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
+                }
+                const unsigned long long fm = __ballot(found >= 0);
+                const uint32_t gsh = (lane & 48u);
+                const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
+                const bool valid = have && (s == 0 || gbits != 0);
+                uint32_t status = 0xFFu, fixed = 0xFFu;
+                if (valid) {
+                    status = (s == 0) ? 0u : 1u;
+                    if (s != 0) {
+                        const uint32_t fl = __builtin_ctz(gbits);
+                        const int fk = __shfl(found, (int)fl, 16);
+                        fixed = 8 * fl + (uint32_t)fk;
+                        if (l == fl) byte ^= 0x80u >> fk;
+                    }
+                }
+                // stage the 24-byte record, then 6 lanes store it as dwords
+                unsigned char *rec = res + g * 24;
+                if (l < 14) rec[8 + l] = (unsigned char)byte;
+                if (l == 14) rec[22] = (unsigned char)status;
+                if (l == 15) rec[23] = (unsigned char)fixed;
+                if (l == 0) {
+                    const uint64_t o64 = sample0 + off;
+                    reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
+                    reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
+                    if (valid) atomicAdd(&misc[8], 1u);
+                }
+                if (have && base_slot != kNoBase && l < 6) {
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);
+                    dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
                 }
             }
-            // stage the 24-byte record, then 6 lanes store it as dwords
-            unsigned char *rec = res + g * 24;
-            if (l < 14) rec[8 + l] = (unsigned char)byte;
-            if (l == 14) rec[22] = (unsigned char)status;
-            if (l == 15) rec[23] = (unsigned char)fixed;
-            if (l == 0) {
-                const uint64_t o64 = sample0 + off;
-                reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
-                reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
-                if (valid) atomicAdd(&misc[8], 1u);
-            }
-            if (have && base_slot != kNoBase && l < 6) {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);
-                dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
+            __syncthreads();
+        }
+        if (total == 0) __syncthreads(); // pair with the barrier inside the loop for misc[8]/[9]
+        if (tid == 0) {
+            Seg e;
+            e.base = misc[9];
+            e.cand = total;
+            e.valid = misc[8];
+            e.pad = 0;
+            p.seg[tile] = e;
+            if (e.valid && p.count_groups) {
+                atomicAdd(&p.grp1[tile >> kGrpShift], e.valid);
+                atomicAdd(&p.grp2[(tile >> (2 * kGrpShift)) * kGrp2Shards + ((tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
             }
         }
-        __syncthreads();
-    }
-    if (total == 0) __syncthreads(); // pair with the barrier inside the loop for misc[8]/[9]
-    if (tid == 0) {
-        Seg e;
-        e.base = misc[9];
-        e.cand = total;
-        e.valid = misc[8];
-        e.pad = 0;
-        p.seg[tile] = e;
     }
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
 template <int ST>
-static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &a, uint32_t n)
+static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &a, uint32_t grid_x)
 {
-    dim3 grid(n), block(kThreads);
+    dim3 grid(grid_x), block(kThreads);
     switch (mag_mode) {
     case 0: hipLaunchKernelGGL((demod_tiles<ST, 0>), grid, block, 0, s, a); break;
     case 1: hipLaunchKernelGGL((demod_tiles<ST, 1>), grid, block, 0, s, a); break;
@@ -503,82 +602,71 @@ static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &
 }
 
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
-                        uint32_t n_tiles_launch)
+                        uint32_t n_compute_units)
 {
-    if (n_tiles_launch == 0) return hipSuccess;
-    if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, n_tiles_launch);
-    return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, n_tiles_launch);
+    (void)n_compute_units;
+    if (a.tile_count == 0) return hipSuccess;
+    if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count);
+    return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count);
 }
 
 // ---- ordering pass ---------------------------------------------------------------------------
-// scan: exclusive prefix of Seg::valid over all tiles (global tile order = channel-major, then
-// ascending offset) -> where each tile's frames go in the final list.
-__global__ __launch_bounds__(1024) void scan_tiles(CompactArgs a)
+// Position of tile t's first frame in the final list = number of valid frames in tiles < t
+// (global tile order = channel-major, then ascending offset).  Wave-cooperative: every lane gets
+// the result.  Saturates at 2^32-1 (such positions are beyond any max_out).
+__device__ __forceinline__ uint32_t tile_prefix(const CompactArgs &a, uint32_t t, uint32_t lane)
 {
-    __shared__ uint32_t wsum[16];
-    __shared__ unsigned long long carry_s;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    int retry = 0;
-    for (uint32_t base = 0; base < a.n_tiles; base += 1024) {
-        const uint32_t t = base + tid;
-        uint32_t v = 0;
-        Seg e = {0, 0, 0, 0};
-        if (t < a.n_tiles) { e = a.seg[t]; v = e.valid; }
-        uint32_t incl = v; // <= 1024 tiles x 32768 frames: fits 32 bits
+    const uint32_t g = t >> kGrpShift, sg = t >> (2 * kGrpShift);
+    unsigned long long sum = 0;
+    for (uint32_t k = lane; k < sg * kGrp2Shards; k += 64) sum += a.grp2[k];
+    { const uint32_t k = (sg << kGrpShift) + lane; if (k < g) sum += a.grp1[k]; }
+    { const uint32_t k = (g << kGrpShift) + lane; if (k < t) sum += a.seg[k].valid; }
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t x = __shfl_up(incl, d, 64);
-            if ((int)lane >= d) incl += x;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t wb = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { uint32_t x = wsum[w]; wb += (w < (int)wave) ? x : 0u; tot += x; }
-        const unsigned long long carry = carry_s;
-        const unsigned long long excl64 = carry + wb + incl - v;
-        const uint32_t excl = excl64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)excl64;
-        if (t < a.n_tiles) {
-            a.out_start[t] = excl; // saturated values are >= max_out, hence never gathered
-            if (v && e.base == kNoBase && excl < a.max_out) retry = 1;
-        }
-        __syncthreads();
-        if (tid == 0) carry_s = carry + tot;
-        __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)sum, d, 64), hi = __shfl_xor((uint32_t)(sum >> 32), d, 64);
+        sum += ((unsigned long long)hi << 32) | lo;
     }
-    retry = __syncthreads_or(retry);
-    if (tid == 0) {
-        const unsigned long long total = carry_s;
-        a.out_start[a.n_tiles] = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
-        a.hdr->total_found = total;
-        a.hdr->n_out = total < a.max_out ? total : a.max_out;
-        a.hdr->flags = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
-        a.hdr->retry = retry ? 1u : 0u;
-        a.hdr->alloc = 0; // ready for the next launch
-    }
-    __syncthreads();
-    // frames per channel, clipped to what fits in max_out
-    for (uint32_t c = tid; c < a.n_channels; c += 1024) {
-        uint32_t b = a.out_start[c * a.tiles_per_channel];
-        uint32_t e = a.out_start[(c + 1) * a.tiles_per_channel];
-        b = b < a.max_out ? b : a.max_out;
-        e = e < a.max_out ? e : a.max_out;
-        a.chan_counts[c] = e - b;
-    }
+    return sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;
 }
 
 // gather: one wave per tile copies its valid slots, in slot (= offset) order, to the final list.
+// Workgroup 0 also writes the header / per-channel counts and re-arms the allocator and ticket
+// dispenser; all workgroups clear the other parity's group counters for the next launch.
 __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t t = a.tile_first + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+        if (a.zero1) for (uint32_t k = gtid; k < a.n_grp1; k += gsz) a.zero1[k] = 0;
+        if (a.zero2) for (uint32_t k = gtid; k < a.n_grp2; k += gsz) a.zero2[k] = 0;
+    }
+    if (blockIdx.x == 0 && wave == 0 && a.write_header) {
+        const unsigned long long total = tile_prefix(a, a.n_tiles, lane); // (saturating)
+        for (uint32_t c0 = 0; c0 < a.n_channels; ++c0) {
+            uint32_t b = tile_prefix(a, c0 * a.tiles_per_channel, lane);
+            uint32_t e = tile_prefix(a, (c0 + 1) * a.tiles_per_channel, lane);
+            b = b < a.max_out ? b : a.max_out;
+            e = e < a.max_out ? e : a.max_out;
+            if (lane == 0) a.chan_counts[c0] = e - b;
+        }
+        if (lane == 0) {
+            a.hdr->total_found = total;
+            a.hdr->n_out = total < a.max_out ? total : a.max_out;
+            a.hdr->flags = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
+            a.hdr->alloc = 0;     // ready for the next launch
+            a.hdr->next_tile = 0;
+        }
+    }
+    const uint32_t t = a.tile_first + blockIdx.x * 4 + wave;
     if (t >= a.tile_first + a.tile_count) return;
     const Seg e = a.seg[t];
-    if (e.valid == 0 || e.base == kNoBase) return;
-    uint32_t pos = a.out_start[t];
+    if (e.valid == 0) return;
+    uint32_t pos = a.out_start ? a.out_start[t] : tile_prefix(a, t, lane);
     if (pos >= a.max_out) return;
+    if (e.base == kNoBase) { // its slots were dropped but its frames are wanted: host re-plans
+        if (lane == 0) atomicOr(&a.hdr->retry, 1u);
+        return;
+    }
     const uint32_t *src = reinterpret_cast<const uint32_t *>(a.slots + e.base);
     for (uint32_t i0 = 0; i0 < e.cand; i0 += 64) {
         const uint32_t i = i0 + lane;
@@ -600,16 +688,11 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
     }
 }
 
-hipError_t launch_scan(hipStream_t s, const CompactArgs &a)
-{
-    hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, s, a);
-    return hipGetLastError();
-}
-
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a)
 {
-    if (a.tile_count == 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_tiles, dim3((a.tile_count + 3) / 4), dim3(256), 0, s, a);
+    uint32_t blocks = (a.tile_count + 3) / 4;
+    if (blocks == 0) blocks = 1; // the header still has to be written
+    hipLaunchKernelGGL(gather_tiles, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -1,13 +1,20 @@
 #!/bin/bash
-# GPU box helper: bench line + rocprofv3 kernel stats of the same command (summaries -> gpurun_out/)
+# GPU box helper: parity tests, bench line, rocprofv3 kernel stats of the same command
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python bench.py --steps ${STEPS:-30} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/parity.log; rc=$?
+  cat gpurun_out/parity.log
+  [ $rc -ne 0 ] && exit $rc
+fi
+python bench.py --steps ${STEPS:-30} --warmup 3 ${BENCH_ARGS:-} > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
 tail -5 gpurun_out/bench.err; cat gpurun_out/bench.json
 [ $rc -ne 0 ] && exit $rc
-rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err; rc=$?
-tail -3 gpurun_out/prof.err; cat gpurun_out/prof_bench.json
-find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
+if [ "${SKIP_PROF:-0}" != "1" ]; then
+  rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err; rc=$?
+  tail -3 gpurun_out/prof.err
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
+fi
 exit $rc
