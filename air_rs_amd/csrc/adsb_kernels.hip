@@ -311,15 +311,20 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
             __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<BPS>(p, tp);
             if (ST == ADSB_SAMPLE_I8) {
                 u32x4 raw[kRawIters];
+                // the last sweep only covers the halo: whole waves past it skip it (scalar branch)
+                const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 8;
 #pragma unroll
                 for (int it = 0; it < kRawIters; ++it)
-                    raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, 0);
+                    if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag)
+                        raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, 0);
 #pragma unroll
                 for (int it = 0; it < kRawIters; ++it) {
-                    uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
-                    uint32_t lo, hi;
-                    mags8_i8<MAGMODE>(raw[it], lo, hi);
-                    if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+                    if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag) {
+                        uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
+                        uint32_t lo, hi;
+                        mags8_i8<MAGMODE>(raw[it], lo, hi);
+                        if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+                    }
                 }
             } else {
                 constexpr int kIters = (kMag + kThreads * 4 - 1) / (kThreads * 4); // 33
@@ -338,7 +343,14 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
         // Run A = offsets [tid*64, +64), run B = [(tid+256)*64, +64) of the tile.
         {
-            uint32_t mA0 = 0, mA1 = 0, mB0 = 0, mB1 = 0; // survivors, bit o of word o>>5
+            // Survivor bitmap: two words per run (bit o of word o>>5), owned by this lane.  The rare
+            // path ORs bits straight into LDS so the 64 unrolled steps carry no mask registers.
+            uint32_t *candA = cand + 2 * tid, *candB = cand + 2 * (tid + kThreads);
+            *reinterpret_cast<uint2 *>(candA) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(candB) = make_uint2(0u, 0u);
+            // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
+            const uint32_t sa = tid * kRun, sb = (tid + kThreads) * kRun;
+            const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
             constexpr int kGran = (kRun + 26 + SPG - 1) / SPG + 1; // granules a run may touch
             const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * kRun);
             const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + kThreads) * kRun);
@@ -353,13 +365,20 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
 
             // Sliding state shared by neighbouring offsets (all indices are compile-time after
             // unrolling): N[j] sample pair, H2[j] = min(N[j], N[j+2]), W3[j] = max(N[j..j+2]).
-            uint32_t N[kRun + 26], H2[kRun + 8], W3[kRun + 16];
+            // Sliding state shared by neighbouring offsets (all indices are compile-time after
+            // unrolling).  With F[j] = max N[j + {0,2,3,4,5}] the twelve low slots of offset o are
+            // F[o+1] u F[o+8] u {o+13,14,15}: one new W3, one new F and one 3-input max per offset.
+            //   N[j]  sample pair             H2[j] = min(N[j], N[j+2])
+            //   W3[j] = max(N[j..j+2])        F[j]  = max(N[j], W3[j+2], N[j+5])
+            uint32_t N[kRun + 26], H2[kRun + 8], W3[kRun + 16], F[kRun + 9];
 #pragma unroll
             for (int k = 0; k < 25; ++k) N[k] = pair_at<ST>(ra, rb, k);
 #pragma unroll
             for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
 #pragma unroll
             for (int j = 3; j < 13; ++j) W3[j] = pkmax3<ST>(N[j], N[j + 1], N[j + 2]);
+#pragma unroll
+            for (int j = 1; j < 8; ++j) F[j] = pkmax3<ST>(N[j], W3[j + 2], N[j + 5]);
 
 #pragma unroll
             for (int o = 0; o < kRun; ++o) {
@@ -375,33 +394,27 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 // samples already in registers
                 N[o + 25] = pair_at<ST>(ra, rb, o + 25);
                 W3[o + 13] = pkmax3<ST>(N[o + 13], N[o + 14], N[o + 15]);
-                const uint32_t w6 = pkmax(W3[o + 10], W3[o + 13]);               // lows 10..15
-                const uint32_t la = pkmax3<ST>(W3[o + 3], N[o + 6], N[o + 1]);   // lows 3,4,5,6 and 1
-                const uint32_t lo = pkmax3<ST>(la, N[o + 8], w6);                 // + low 8
+                F[o + 8] = pkmax3<ST>(N[o + 8], W3[o + 10], N[o + 13]);           // lows 8,10,11,12,13
+                const uint32_t lo = pkmax3<ST>(F[o + 1], F[o + 8], W3[o + 13]);   // + 1,3,4,5,6 + 13,14,15
                 H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
                 const uint32_t hi = pkmin(H2[o], H2[o + 7]);                      // highs 0,2,7,9
                 const bool pa = (uint16_t)hi >= (uint16_t)lo;
                 const bool pb = (hi >> 16) >= (lo >> 16);
-                if (pa | pb) {
+                // wave-uniform test (a scalar branch, no exec juggling): the block below is entered by
+                // the whole wave when any lane passes; its effects are masked by pa/pb anyway
+                if (__builtin_amdgcn_ballot_w64(pa | pb) != 0) {
                     // DF17 part of the gate (demod.rs:45-54)
                     const uint32_t dh = pkmin3<ST>(pkmin3<ST>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
                     const uint32_t dl = pkmax3<ST>(pkmax3<ST>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
                     const bool da = (uint16_t)dh >= (uint16_t)dl;
                     const bool db = (dh >> 16) >= (dl >> 16);
                     const uint32_t bit = 1u << (o & 31);
-                    if (o < 32) { mA0 |= (pa & da) ? bit : 0u; mB0 |= (pb & db) ? bit : 0u; }
-                    else        { mA1 |= (pa & da) ? bit : 0u; mB1 |= (pb & db) ? bit : 0u; }
+                    if (pa & da & ((uint32_t)o < va)) atomicOr(candA + (o >> 5), bit);
+                    if (pb & db & ((uint32_t)o < vb)) atomicOr(candB + (o >> 5), bit);
                 }
             }
-            // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
-            const uint32_t sa = tid * kRun, sb = (tid + kThreads) * kRun;
-            const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
-            mA0 &= va >= 32 ? 0xFFFFFFFFu : ((1u << va) - 1u);
-            mA1 &= va >= 64 ? 0xFFFFFFFFu : (va > 32 ? ((1u << (va - 32)) - 1u) : 0u);
-            mB0 &= vb >= 32 ? 0xFFFFFFFFu : ((1u << vb) - 1u);
-            mB1 &= vb >= 64 ? 0xFFFFFFFFu : (vb > 32 ? ((1u << (vb - 32)) - 1u) : 0u);
-            *reinterpret_cast<uint2 *>(cand + 2 * tid) = make_uint2(mA0, mA1);
-            *reinterpret_cast<uint2 *>(cand + 2 * (tid + kThreads)) = make_uint2(mB0, mB1);
+            const uint2 ma = *reinterpret_cast<const uint2 *>(candA), mb = *reinterpret_cast<const uint2 *>(candB);
+            const uint32_t mA0 = ma.x, mA1 = ma.y, mB0 = mb.x, mB1 = mb.y;
             // Survivors are rare (a handful per tile): the few lanes that have any append their
             // offsets, unordered, to the list; wave 0 ranks them afterwards.  The bitmap above is
             // only read if there turn out to be more than kSparseCap.

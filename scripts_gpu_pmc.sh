@@ -6,15 +6,13 @@ mkdir -p gpurun_out/pmc
 run_pass() {
   name=$1; shift
   rm -rf gpurun_out/pmc/$name
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$name -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/pmc/$name.json 2> gpurun_out/pmc/$name.err || { tail -5 gpurun_out/pmc/$name.err; return 1; }
+  echo "pass $name" >> gpurun_out/pmc/progress.txt
+  timeout -k 5 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$name -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/pmc/$name.json 2> gpurun_out/pmc/$name.err || { tail -5 gpurun_out/pmc/$name.err; return 1; }
 }
 run_pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU || exit 1
 run_pass sq2 SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_WAVES || exit 1
 run_pass sq3 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_IFETCH SQ_BUSY_CU_CYCLES SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_LDS_UNALIGNED_STALL || exit 1
-run_pass sq4 SQ_LEVEL_WAVES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH_LEVEL || exit 1
 run_pass tcc1 FETCH_SIZE GRBM_GUI_ACTIVE || exit 1
-run_pass tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 1
-run_pass ta1 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum || exit 1
 python3 - <<'PY'
 import csv, glob, collections, json
 res = collections.defaultdict(lambda: collections.defaultdict(list))
