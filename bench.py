@@ -71,10 +71,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = args.samples
+    cfg = A.synth_default()
+    cfg_slot = cfg.slot_len
     own = n - A.WINDOW                      # offsets this rank owns
     first = rank * own                      # its slice of the long stream (240-sample read halo)
-    cap = n // 1500 + 4096                  # frame capacity: 1 slot / 2000 samples + margin
-    cfg = A.synth_default()
+    cap = n // cfg_slot + 8192              # frame capacity: at most one frame per slot, + margin for noise
     stream = torch.cuda.current_stream()
     dem = A.AdsbDemod(device=local_rank, sample_type=A.ADSB_SAMPLE_I8, max_samples=n, max_out=cap,
                       stream=stream.cuda_stream, host_staging=False)
@@ -95,6 +96,7 @@ def main():
 
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    hip.hipMemcpyAsync.restype = ctypes.c_int
 
     pending = [None, None]
 
@@ -106,8 +108,10 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()
             # D2D: header + frame list into the staging buffer (same stream, ordered after the kernels)
-            hip.hipMemcpyAsync(stage[b].data_ptr(), hdr_ptr, 32, 3, stream.cuda_stream)
-            hip.hipMemcpyAsync(stage[b].data_ptr() + 32, frames_ptr, cap * rec, 3, stream.cuda_stream)
+            e1 = hip.hipMemcpyAsync(stage[b].data_ptr(), hdr_ptr, 32, 3, stream.cuda_stream)
+            e2 = hip.hipMemcpyAsync(stage[b].data_ptr() + 32, frames_ptr, cap * rec, 3, stream.cuda_stream)
+            if e1 or e2:
+                raise RuntimeError(f"hipMemcpyAsync failed: {e1} {e2}")
             pending[b] = dist.gather(stage[b], recv[b], dst=0, async_op=True)
 
     def drain():
