@@ -57,7 +57,7 @@ struct adsb_ctx {
 
     // timing
     bool timing = false;
-    hipEvent_t ev[kTimingRing][3] = {};
+    hipEvent_t ev[kTimingRing][4] = {};
     bool ev_made = false;
     uint32_t ev_count = 0;
 };
@@ -267,17 +267,13 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
             c->ev_made = true;
         }
         ev = c->ev[c->ev_count % kTimingRing];
-        HIPCHK(hipEventRecord(ev[0], c->stream));
     }
     HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode,
-                               demod_args(c, 0, c->last_tiles, true), c->n_cu));
-    if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
-    HIPCHK(adsbk::launch_gather(c->stream, compact_args(c, 0, c->last_tiles, false)));
+                               demod_args(c, 0, c->last_tiles, true), ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
+    HIPCHK(adsbk::launch_gather(c->stream, compact_args(c, 0, c->last_tiles, false), ev ? ev[2] : nullptr,
+                                ev ? ev[3] : nullptr));
     c->parity ^= 1u; // the gather just cleared the other set for the next launch
-    if (ev) {
-        HIPCHK(hipEventRecord(ev[2], c->stream));
-        c->ev_count++;
-    }
+    if (ev && c->last_tiles) c->ev_count++;
     return ADSB_OK;
 }
 
@@ -311,7 +307,7 @@ static int rerun_in_batches(adsb_ctx *c)
         hipError_t e;
         if ((e = hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream)) != hipSuccess ||
             (e = hipMemsetAsync(&c->hdr->next_tile, 0, sizeof(uint32_t), c->stream)) != hipSuccess ||
-            (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, t0, t1 - t0, false), c->n_cu)) != hipSuccess ||
+            (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, t0, t1 - t0, false))) != hipSuccess ||
             (e = adsbk::launch_gather(c->stream, compact_args(c, t0, t1 - t0, true))) != hipSuccess)
             rc = (int)e;
         t0 = t1;
@@ -422,7 +418,7 @@ extern "C" int adsb_timing_read(adsb_ctx *c, double *demod_ms, double *order_ms,
     for (uint32_t k = 0; k < n; ++k) {
         float x = 0, y = 0;
         HIPCHK(hipEventElapsedTime(&x, c->ev[k][0], c->ev[k][1]));
-        HIPCHK(hipEventElapsedTime(&y, c->ev[k][1], c->ev[k][2]));
+        HIPCHK(hipEventElapsedTime(&y, c->ev[k][2], c->ev[k][3]));
         a += x;
         b += y;
     }

@@ -92,9 +92,11 @@ struct CompactArgs {
 //   2: rounds to nearest regardless -> subtract 0.5 first.
 hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]);
 
+// e0/e1: optional events recorded at the start / end of the dispatch itself (nullptr: none)
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
-                        uint32_t n_compute_units);
-hipError_t launch_gather(hipStream_t s, const CompactArgs &a);
+                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nullptr,
+                         hipEvent_t e1 = nullptr);
 
 // test / measurement kernels
 hipError_t launch_magnitudes(hipStream_t s, int sample_type, int mag_mode, const void *iq,

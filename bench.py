@@ -124,7 +124,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
-    dem.timing_enable(True)
+    dem.timing_enable(os.environ.get("ADSB_BENCH_NO_TIMING") != "1")
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
