@@ -31,19 +31,28 @@ struct adsb_ctx {
 
     // device buffers
     void *staging = nullptr;        // host-fed input (cfg.host_staging)
-    adsbk::Seg *seg = nullptr;      // [n_tiles_max]
+    // Two result sets, used alternately: the ordering pass of launch i runs on `aux` while the
+    // demod kernel of launch i+1 already runs on `stream` (they touch different sets).
+    struct ResultSet {
+        adsbk::Seg *seg = nullptr;       // [n_tiles_max]
+        adsb_frame *slots = nullptr;     // [n_tiles_max * kQuota] fixed region, then the pool [cap_slots]
+        adsb_frame *out = nullptr;       // [max_out]
+        adsbk::Header *hdr = nullptr;
+        uint64_t *chan_counts = nullptr; // [max_channels]
+        hipEvent_t k_done = nullptr, g_done = nullptr;
+        bool g_pending = false;
+    } rs[2];
+    hipStream_t aux = nullptr;      // ordering pass + result copies (== stream unless ADSB_OVERLAP_ORDERING=1)
+    bool own_aux = false;
+    uint32_t launch_idx = 0;        // launches so far
+    uint32_t last = 0;              // result set of the last launch
     uint32_t *out_start = nullptr;  // [n_tiles_max + 1]  (slot-overflow re-run path only)
-    uint32_t *grp = nullptr;        // two parities x (grp1[n_grp1] | grp2[n_grp2]) valid-frame counters
+    uint32_t *grp = nullptr;        // three sets x (grp1[n_grp1] | grp2[n_grp2]) valid-frame counters
     uint32_t n_grp1 = 0, n_grp2 = 0;
-    uint32_t parity = 0;            // which counter set the next launch uses
-    uint32_t n_cu = 256;
-    uint64_t *chan_counts = nullptr;// [max_channels]
-    adsb_frame *slots = nullptr;    // [cap_slots]
-    adsb_frame *out = nullptr;      // [max_out]
-    adsbk::Header *hdr = nullptr;
     uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
+    uint32_t n_cu = 256;
 
     // pinned host mirrors
     adsbk::Header *hdr_host = nullptr;
@@ -98,15 +107,21 @@ extern "C" void adsb_destroy(adsb_ctx *c)
         for (auto &e : c->ev)
             for (auto &x : e)
                 if (x) (void)hipEventDestroy(x);
+    if (c->own_aux && c->aux) (void)hipStreamSynchronize(c->aux);
     (void)hipFree(c->staging);
-    (void)hipFree(c->seg);
+    for (auto &r : c->rs) {
+        (void)hipFree(r.seg);
+        (void)hipFree(r.slots);
+        (void)hipFree(r.out);
+        (void)hipFree(r.hdr);
+        (void)hipFree(r.chan_counts);
+        if (r.k_done) (void)hipEventDestroy(r.k_done);
+        if (r.g_done) (void)hipEventDestroy(r.g_done);
+    }
     (void)hipFree(c->out_start);
-    (void)hipFree(c->chan_counts);
-    (void)hipFree(c->slots);
-    (void)hipFree(c->out);
-    (void)hipFree(c->hdr);
     (void)hipFree(c->scratch);
     (void)hipFree(c->grp);
+    if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -154,26 +169,42 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
             e = hipMalloc(&c->staging, stride * cfg->max_channels * c->bps + 64);
             if (e != hipSuccess) { fail(ADSB_E_NOMEM); break; }
         }
-        if ((e = hipMalloc((void **)&c->seg, sizeof(adsbk::Seg) * (size_t)c->n_tiles_max)) != hipSuccess ||
-            (e = hipMalloc((void **)&c->out_start, sizeof(uint32_t) * ((size_t)c->n_tiles_max + 1))) != hipSuccess ||
-            (e = hipMalloc((void **)&c->chan_counts, sizeof(uint64_t) * cfg->max_channels)) != hipSuccess ||
-            (e = hipMalloc((void **)&c->slots, sizeof(adsb_frame) * ((size_t)c->n_tiles_max * adsbk::kQuota + c->cap_slots))) != hipSuccess ||
-            (e = hipMalloc((void **)&c->out, sizeof(adsb_frame) * (size_t)cfg->max_out)) != hipSuccess ||
-            (e = hipMalloc((void **)&c->hdr, sizeof(adsbk::Header))) != hipSuccess ||
-            (e = hipMalloc((void **)&c->scratch, 64)) != hipSuccess ||
-            (e = hipMalloc((void **)&c->grp, sizeof(uint32_t) * 2 * ((size_t)c->n_grp1 + c->n_grp2))) != hipSuccess) {
-            fail(ADSB_E_NOMEM);
-            break;
+        // The ordering pass normally follows the demod kernel on the same stream.  Running it on its
+        // own stream (ADSB_OVERLAP_ORDERING=1) lets it overlap the next launch's kernel, but measured
+        // slower on MI355X: the tiny gather then competes with 16 k workgroups for CUs (26 us
+        // instead of 9) and the step does not get shorter.
+        const char *ov = getenv("ADSB_OVERLAP_ORDERING");
+        if (ov && ov[0] == '1') {
+            if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
+            c->own_aux = true;
+        } else {
+            c->aux = c->stream;
         }
-        if (hipMemsetAsync(c->grp, 0, sizeof(uint32_t) * 2 * ((size_t)c->n_grp1 + c->n_grp2), c->stream) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
+        const size_t n_slots = (size_t)c->n_tiles_max * adsbk::kQuota + c->cap_slots;
+        bool ok = true;
+        for (auto &r : c->rs) {
+            ok = ok && hipMalloc((void **)&r.seg, sizeof(adsbk::Seg) * (size_t)c->n_tiles_max) == hipSuccess &&
+                 hipMalloc((void **)&r.slots, sizeof(adsb_frame) * n_slots) == hipSuccess &&
+                 hipMalloc((void **)&r.out, sizeof(adsb_frame) * (size_t)cfg->max_out) == hipSuccess &&
+                 hipMalloc((void **)&r.hdr, sizeof(adsbk::Header)) == hipSuccess &&
+                 hipMalloc((void **)&r.chan_counts, sizeof(uint64_t) * cfg->max_channels) == hipSuccess &&
+                 hipEventCreateWithFlags(&r.k_done, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&r.g_done, hipEventDisableTiming) == hipSuccess &&
+                 hipMemsetAsync(r.hdr, 0, sizeof(adsbk::Header), c->stream) == hipSuccess;
+        }
+        const size_t grp_words = 3 * ((size_t)c->n_grp1 + c->n_grp2);
+        ok = ok && hipMalloc((void **)&c->out_start, sizeof(uint32_t) * ((size_t)c->n_tiles_max + 1)) == hipSuccess &&
+             hipMalloc((void **)&c->scratch, 64) == hipSuccess &&
+             hipMalloc((void **)&c->grp, sizeof(uint32_t) * grp_words) == hipSuccess &&
+             hipMemsetAsync(c->grp, 0, sizeof(uint32_t) * grp_words, c->stream) == hipSuccess &&
+             hipMemsetAsync(c->scratch, 0, 64, c->stream) == hipSuccess;
+        if (!ok) { fail(ADSB_E_NOMEM); break; }
         {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
                 c->n_cu = (uint32_t)prop.multiProcessorCount;
         }
         if (hipHostMalloc((void **)&c->hdr_host, sizeof(adsbk::Header), hipHostMallocDefault) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
-        if (hipMemsetAsync(c->hdr, 0, sizeof(adsbk::Header), c->stream) != hipSuccess ||
-            hipMemsetAsync(c->scratch, 0, 64, c->stream) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
         uint32_t probe[4] = {0, 0, 0, 0};
         e = adsbk::probe_cvt(c->stream, c->scratch, probe);
         if (e != hipSuccess) { fail((int)e); break; }
@@ -192,10 +223,11 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
 extern "C" void *adsb_stream(adsb_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
 
-static uint32_t *grp1_of(adsb_ctx *c, uint32_t parity) { return c->grp + (size_t)parity * (c->n_grp1 + c->n_grp2); }
-static uint32_t *grp2_of(adsb_ctx *c, uint32_t parity) { return grp1_of(c, parity) + c->n_grp1; }
+static uint32_t *grp1_of(adsb_ctx *c, uint32_t set) { return c->grp + (size_t)set * (c->n_grp1 + c->n_grp2); }
+static uint32_t *grp2_of(adsb_ctx *c, uint32_t set) { return grp1_of(c, set) + c->n_grp1; }
 
-static adsbk::DemodArgs demod_args(adsb_ctx *c, uint32_t tile_first, uint32_t tile_count, bool count_groups)
+static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t grp_set, uint32_t tile_first,
+                                   uint32_t tile_count, bool count_groups)
 {
     adsbk::DemodArgs a{};
     a.iq = c->last_iq;
@@ -205,30 +237,31 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, uint32_t tile_first, uint32_t ti
     a.tile_first = tile_first;
     a.tile_count = tile_count;
     a.count_groups = count_groups ? 1u : 0u;
-    a.seg = c->seg;
-    a.slots = c->slots;
+    a.seg = r.seg;
+    a.slots = r.slots;
     a.pool_first = c->n_tiles_max * adsbk::kQuota;
     a.cap_slots = c->cap_slots;
-    a.hdr = c->hdr;
-    a.grp1 = grp1_of(c, c->parity);
-    a.grp2 = grp2_of(c, c->parity);
+    a.hdr = r.hdr;
+    a.grp1 = grp1_of(c, grp_set);
+    a.grp2 = grp2_of(c, grp_set);
     return a;
 }
 
-static adsbk::CompactArgs compact_args(adsb_ctx *c, uint32_t tile_first, uint32_t tile_count, bool rerun)
+static adsbk::CompactArgs compact_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t grp_set, int zero_set,
+                                       uint32_t tile_first, uint32_t tile_count, bool rerun)
 {
     adsbk::CompactArgs a{};
-    a.seg = c->seg;
-    a.slots = c->slots;
+    a.seg = r.seg;
+    a.slots = r.slots;
     a.out_start = rerun ? c->out_start : nullptr;
-    a.grp1 = grp1_of(c, c->parity);
-    a.grp2 = grp2_of(c, c->parity);
-    a.zero1 = rerun ? nullptr : grp1_of(c, c->parity ^ 1u);
-    a.zero2 = rerun ? nullptr : grp2_of(c, c->parity ^ 1u);
+    a.grp1 = grp1_of(c, grp_set);
+    a.grp2 = grp2_of(c, grp_set);
+    a.zero1 = zero_set >= 0 ? grp1_of(c, (uint32_t)zero_set) : nullptr;
+    a.zero2 = zero_set >= 0 ? grp2_of(c, (uint32_t)zero_set) : nullptr;
     a.n_grp1 = c->n_grp1;
     a.n_grp2 = c->n_grp2;
-    a.chan_counts = c->chan_counts;
-    a.out = c->out;
+    a.chan_counts = r.chan_counts;
+    a.out = r.out;
     a.n_tiles = c->last_tiles;
     a.tiles_per_channel = c->last_tpc;
     a.n_channels = c->last_channels;
@@ -236,7 +269,7 @@ static adsbk::CompactArgs compact_args(adsb_ctx *c, uint32_t tile_first, uint32_
     a.tile_first = tile_first;
     a.tile_count = tile_count;
     a.write_header = rerun ? 0u : 1u;
-    a.hdr = c->hdr;
+    a.hdr = r.hdr;
     return a;
 }
 
@@ -259,6 +292,13 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_tiles = c->last_tpc * n_channels;
     c->launched = true;
 
+    // Launch i uses result set i&1 and counter set i%3; its ordering pass clears counter set
+    // (i+2)%3 for launch i+2.  The demod kernel only has to wait for the ordering pass of launch
+    // i-2 (same result set), so ordering pass i and demod kernel i+1 overlap.
+    const uint32_t i = c->launch_idx;
+    adsb_ctx::ResultSet &r = c->rs[i & 1u];
+    if (c->own_aux && r.g_pending) HIPCHK(hipStreamWaitEvent(c->stream, r.g_done, 0));
+
     hipEvent_t *ev = nullptr;
     if (c->timing) {
         if (!c->ev_made) {
@@ -269,22 +309,33 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
         ev = c->ev[c->ev_count % kTimingRing];
     }
     HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode,
-                               demod_args(c, 0, c->last_tiles, true), ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
-    HIPCHK(adsbk::launch_gather(c->stream, compact_args(c, 0, c->last_tiles, false), ev ? ev[2] : nullptr,
-                                ev ? ev[3] : nullptr));
-    c->parity ^= 1u; // the gather just cleared the other set for the next launch
+                               demod_args(c, r, i % 3u, 0, c->last_tiles, true), ev ? ev[0] : nullptr,
+                               ev ? ev[1] : nullptr));
+    if (c->own_aux) {
+        HIPCHK(hipEventRecord(r.k_done, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->aux, r.k_done, 0));
+    }
+    HIPCHK(adsbk::launch_gather(c->aux, compact_args(c, r, i % 3u, (int)((i + 2u) % 3u), 0, c->last_tiles, false),
+                                ev ? ev[2] : nullptr, ev ? ev[3] : nullptr));
+    HIPCHK(hipEventRecord(r.g_done, c->aux));
+    r.g_pending = true;
+    c->last = i & 1u;
+    c->launch_idx = i + 1u;
     if (ev && c->last_tiles) c->ev_count++;
     return ADSB_OK;
 }
 
-// Slot-store overflow (far more gate survivors than max_out + one tile): redo the tiles that feed
+// Slot-pool overflow (far more gate survivors than max_out + one tile): redo the tiles that feed
 // the first max_out frames in batches whose survivors fit.  Counts from the first pass are exact,
 // so the plan is made on the host.  Only pathological inputs get here.
-static int rerun_in_batches(adsb_ctx *c)
+static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
 {
+    HIPCHK(hipStreamSynchronize(c->aux));
+    HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t n = c->last_tiles;
+    const uint32_t grp_set = (c->launch_idx + 2u) % 3u; // == (launch_idx - 1) % 3: read-only here
     std::vector<adsbk::Seg> seg(n);
-    HIPCHK(hipMemcpyAsync(seg.data(), c->seg, sizeof(adsbk::Seg) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(seg.data(), r.seg, sizeof(adsbk::Seg) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<uint32_t> start((size_t)n + 1);
     uint64_t run = 0;
@@ -295,7 +346,6 @@ static int rerun_in_batches(adsb_ctx *c)
     HIPCHK(hipMemcpyAsync(c->out_start, start.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
     uint32_t limit = 0;
     while (limit < n && start[limit] < (uint32_t)c->cfg.max_out) ++limit;
-    c->parity ^= 1u; // point back at the counter set the first pass filled (read-only here)
     uint32_t t0 = 0;
     int rc = ADSB_OK;
     while (t0 < limit && rc == ADSB_OK) {
@@ -305,17 +355,16 @@ static int rerun_in_batches(adsb_ctx *c)
         while (t1 < limit && used + pool_need(t1) <= c->cap_slots) used += pool_need(t1++);
         if (t1 == t0) { rc = ADSB_E_STATE; break; } // a single tile never exceeds cap_slots (>= kTile)
         hipError_t e;
-        if ((e = hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream)) != hipSuccess ||
-            (e = hipMemsetAsync(&c->hdr->next_tile, 0, sizeof(uint32_t), c->stream)) != hipSuccess ||
-            (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, demod_args(c, t0, t1 - t0, false))) != hipSuccess ||
-            (e = adsbk::launch_gather(c->stream, compact_args(c, t0, t1 - t0, true))) != hipSuccess)
+        if ((e = hipMemsetAsync(&r.hdr->alloc, 0, sizeof(unsigned long long), c->stream)) != hipSuccess ||
+            (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode,
+                                     demod_args(c, r, grp_set, t0, t1 - t0, false))) != hipSuccess ||
+            (e = adsbk::launch_gather(c->stream, compact_args(c, r, grp_set, -1, t0, t1 - t0, true))) != hipSuccess)
             rc = (int)e;
         t0 = t1;
     }
-    c->parity ^= 1u;
-    HIPCHK(hipMemsetAsync(&c->hdr->alloc, 0, sizeof(unsigned long long), c->stream));
-    HIPCHK(hipMemsetAsync(&c->hdr->next_tile, 0, sizeof(uint32_t), c->stream));
-    HIPCHK(hipMemsetAsync(&c->hdr->retry, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(&r.hdr->alloc, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(&r.hdr->retry, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return rc;
 }
 
@@ -323,12 +372,12 @@ static int sync_header(adsb_ctx *c)
 {
     if (!c->launched) return ADSB_E_STATE;
     HIPCHK(hipSetDevice(c->cfg.device));
-    HIPCHK(hipMemcpyAsync(c->hdr_host, c->hdr, sizeof(adsbk::Header), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    adsb_ctx::ResultSet &r = c->rs[c->last];
+    HIPCHK(hipMemcpyAsync(c->hdr_host, r.hdr, sizeof(adsbk::Header), hipMemcpyDeviceToHost, c->aux));
+    HIPCHK(hipStreamSynchronize(c->aux)); // the ordering pass of the last launch ran on aux before this copy
     if (c->hdr_host->retry) {
-        int rc = rerun_in_batches(c);
+        int rc = rerun_in_batches(c, r);
         if (rc != ADSB_OK) return rc;
-        HIPCHK(hipStreamSynchronize(c->stream));
         c->hdr_host->retry = 0;
     }
     return ADSB_OK;
@@ -354,13 +403,14 @@ extern "C" int adsb_fetch(adsb_ctx *c, adsb_frame *out, size_t max_out, size_t *
     uint64_t n = c->hdr_host->n_out;
     uint32_t fl = c->hdr_host->flags;
     if (n > max_out) { n = max_out; fl |= ADSB_FLAG_TRUNCATED; }
-    if (n) HIPCHK(hipMemcpyAsync(out, c->out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, c->stream));
+    adsb_ctx::ResultSet &r = c->rs[c->last];
+    if (n) HIPCHK(hipMemcpyAsync(out, r.out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, c->aux));
     std::vector<uint64_t> cc;
     if (per_channel_counts) {
-        HIPCHK(hipMemcpyAsync(per_channel_counts, c->chan_counts, sizeof(uint64_t) * c->last_channels,
-                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(per_channel_counts, r.chan_counts, sizeof(uint64_t) * c->last_channels,
+                              hipMemcpyDeviceToHost, c->aux));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->aux));
     if (per_channel_counts && n < c->hdr_host->n_out) { // caller's array was the tighter cap
         uint64_t left = n;
         for (uint32_t k = 0; k < c->last_channels; ++k) {
@@ -378,8 +428,17 @@ extern "C" int adsb_fetch(adsb_ctx *c, adsb_frame *out, size_t max_out, size_t *
 extern "C" int adsb_result_device(adsb_ctx *c, const adsb_frame **frames_dev, const void **header_dev)
 {
     if (!c) return ADSB_E_ARG;
-    if (frames_dev) *frames_dev = c->out;
-    if (header_dev) *header_dev = c->hdr;
+    if (frames_dev) *frames_dev = c->rs[c->last].out;
+    if (header_dev) *header_dev = c->rs[c->last].hdr;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_stream_wait_results(adsb_ctx *c, void *stream)
+{
+    if (!c) return ADSB_E_ARG;
+    if (!c->launched) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->rs[c->last].g_done, 0));
     return ADSB_OK;
 }
 
@@ -413,6 +472,7 @@ extern "C" int adsb_timing_read(adsb_ctx *c, double *demod_ms, double *order_ms,
     if (!c) return ADSB_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->aux));
     uint32_t n = std::min<uint32_t>(c->ev_count, kTimingRing);
     double a = 0, b = 0;
     for (uint32_t k = 0; k < n; ++k) {

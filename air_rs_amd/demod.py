@@ -137,6 +137,10 @@ class AdsbDemod:
                 "adsb_result_device")
         return frames.value, hdr.value
 
+    def stream_wait_results(self, stream):
+        """Make `stream` (hipStream_t as int) wait for the last launch's ordered frame list."""
+        L.check(self._lib.adsb_stream_wait_results(self._h, stream), "adsb_stream_wait_results")
+
     # -- measurement / test helpers -------------------------------------------------------------------
     def timing_enable(self, on=True):
         L.check(self._lib.adsb_timing_enable(self._h, 1 if on else 0), "adsb_timing_enable")

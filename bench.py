@@ -83,9 +83,9 @@ def main():
     dem.synth_fill_device(cfg, 0, first, n, iq.data_ptr())
     torch.cuda.synchronize()
 
-    frames_ptr, hdr_ptr = dem.result_device()
     rec = 24
     gather_bufs = None
+    side = None
     if world > 1:
         # double-buffered [header(32 B) | cap frames] staging so step i's gather overlaps step i+1
         payload = 32 + cap * rec
@@ -93,32 +93,48 @@ def main():
         recv = [[torch.empty(payload, dtype=torch.uint8, device="cuda") for _ in range(world)]
                 if rank == 0 else None for _ in range(2)]
         gather_bufs = (stage, recv)
+        side = torch.cuda.Stream()
 
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     hip.hipMemcpyAsync.restype = ctypes.c_int
 
     pending = [None, None]
+    copied = [None, None]
+    launched = [False]
 
     def step(i):
+        b = i & 1
+        if world > 1 and copied[b] is not None:
+            stream.wait_event(copied[b])  # launch i reuses the result set step i-2 was copied from
         dem.demod_device_async(iq.data_ptr(), n)
+        launched[0] = True
         if world > 1:
             stage, recv = gather_bufs
-            b = i & 1
-            if pending[b] is not None:
-                pending[b].wait()
-            # D2D: header + frame list into the staging buffer (same stream, ordered after the kernels)
-            e1 = hip.hipMemcpyAsync(stage[b].data_ptr(), hdr_ptr, 32, 3, stream.cuda_stream)
-            e2 = hip.hipMemcpyAsync(stage[b].data_ptr() + 32, frames_ptr, cap * rec, 3, stream.cuda_stream)
-            if e1 or e2:
-                raise RuntimeError(f"hipMemcpyAsync failed: {e1} {e2}")
-            pending[b] = dist.gather(stage[b], recv[b], dst=0, async_op=True)
+            frames_ptr, hdr_ptr = dem.result_device()
+            # the ordered list of this launch is produced on the ctx's internal stream; copy + gather
+            # it from a side stream so the next launch's kernel is not held up
+            dem.stream_wait_results(side.cuda_stream)
+            with torch.cuda.stream(side):
+                if pending[b] is not None:
+                    pending[b].wait()
+                e1 = hip.hipMemcpyAsync(stage[b].data_ptr(), hdr_ptr, 32, 3, side.cuda_stream)
+                e2 = hip.hipMemcpyAsync(stage[b].data_ptr() + 32, frames_ptr, cap * rec, 3, side.cuda_stream)
+                if e1 or e2:
+                    raise RuntimeError(f"hipMemcpyAsync failed: {e1} {e2}")
+                copied[b] = side.record_event()
+                pending[b] = dist.gather(stage[b], recv[b], dst=0, async_op=True)
 
     def drain():
         for b in (0, 1):
             if pending[b] is not None:
-                pending[b].wait()
+                with torch.cuda.stream(side):
+                    pending[b].wait()
                 pending[b] = None
+        if side is not None:
+            side.synchronize()
+        if launched[0]:
+            dem.fetch_counts()  # waits for the last ordering pass
         torch.cuda.synchronize()
 
     for i in range(args.warmup):

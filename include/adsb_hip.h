@@ -122,11 +122,15 @@ int adsb_fetch_counts(adsb_ctx *ctx, uint64_t *n_out, uint64_t *total_found, uin
 
 /*
  * Zero-copy access for device-side consumers (e.g. an RCCL gather of the packet list):
- *   frames_dev : adsb_frame[ ] in device memory, valid until the next launch on this ctx
+ *   frames_dev : adsb_frame[ ] in device memory
  *   header_dev : device pointer to { uint64 n_out; uint64 total_found; uint32 flags; ... }
- * Does not synchronise; order against the ctx stream.
+ * Order a consumer stream behind the launch that fills them with adsb_stream_wait_results().
+ * A context alternates between two result sets, so these pointers stay valid (and unchanged) until
+ * the second-next adsb_demod_device_async() on this context.
  */
 int adsb_result_device(adsb_ctx *ctx, const adsb_frame **frames_dev, const void **header_dev);
+/* Makes `stream` (hipStream_t) wait for the results of the last launch; does not block the host. */
+int adsb_stream_wait_results(adsb_ctx *ctx, void *stream);
 
 /* The stream the ctx enqueues on (hipStream_t as void*). */
 void *adsb_stream(adsb_ctx *ctx);
