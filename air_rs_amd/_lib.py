@@ -66,6 +66,7 @@ PROTOTYPES = {
     "adsb_result_device": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p)]),
     "adsb_stream": (C.c_void_p, [C.c_void_p]),
     "adsb_stream_wait_results": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adsb_set_result_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "adsb_timing_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_uint32)]),
     "adsb_time_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, _P(C.c_double)]),

@@ -44,6 +44,10 @@ struct adsb_ctx {
     } rs[2];
     hipStream_t aux = nullptr;      // ordering pass + result copies (== stream unless ADSB_OVERLAP_ORDERING=1)
     bool own_aux = false;
+    void *ext_blob = nullptr;       // caller-owned [32-byte header | frames] target for the next launches
+    size_t ext_frames = 0;          // frame capacity of ext_blob
+    adsb_frame *last_out = nullptr; // where the last launch's ordered list went
+    uint32_t last_cap = 0;
     uint32_t launch_idx = 0;        // launches so far
     uint32_t last = 0;              // result set of the last launch
     uint32_t *out_start = nullptr;  // [n_tiles_max + 1]  (slot-overflow re-run path only)
@@ -188,8 +192,8 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
                  hipMalloc((void **)&r.out, sizeof(adsb_frame) * (size_t)cfg->max_out) == hipSuccess &&
                  hipMalloc((void **)&r.hdr, sizeof(adsbk::Header)) == hipSuccess &&
                  hipMalloc((void **)&r.chan_counts, sizeof(uint64_t) * cfg->max_channels) == hipSuccess &&
-                 hipEventCreateWithFlags(&r.k_done, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&r.g_done, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&r.k_done, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
+                 hipEventCreateWithFlags(&r.g_done, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
                  hipMemsetAsync(r.hdr, 0, sizeof(adsbk::Header), c->stream) == hipSuccess;
         }
         const size_t grp_words = 3 * ((size_t)c->n_grp1 + c->n_grp2);
@@ -261,11 +265,14 @@ static adsbk::CompactArgs compact_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint
     a.n_grp1 = c->n_grp1;
     a.n_grp2 = c->n_grp2;
     a.chan_counts = r.chan_counts;
-    a.out = r.out;
+    const bool ext = c->ext_blob && !rerun;
+    a.out = ext ? reinterpret_cast<adsb_frame *>(static_cast<char *>(c->ext_blob) + 32) : r.out;
+    a.hdr_pub = ext ? static_cast<uint64_t *>(c->ext_blob) : nullptr;
     a.n_tiles = c->last_tiles;
     a.tiles_per_channel = c->last_tpc;
     a.n_channels = c->last_channels;
-    a.max_out = (uint32_t)c->cfg.max_out;
+    a.max_out = ext ? (uint32_t)std::min<size_t>(c->ext_frames, c->cfg.max_out) : (uint32_t)c->cfg.max_out;
+    if (rerun) { a.out = c->last_out; a.max_out = c->last_cap; }
     a.tile_first = tile_first;
     a.tile_count = tile_count;
     a.write_header = rerun ? 0u : 1u;
@@ -303,7 +310,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     if (c->timing) {
         if (!c->ev_made) {
             for (auto &e : c->ev)
-                for (auto &x : e) HIPCHK(hipEventCreate(&x));
+                for (auto &x : e) HIPCHK(hipEventCreateWithFlags(&x, hipEventReleaseToDevice)); // no system-scope flush
             c->ev_made = true;
         }
         ev = c->ev[c->ev_count % kTimingRing];
@@ -319,6 +326,8 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
                                 ev ? ev[2] : nullptr, ev ? ev[3] : nullptr));
     HIPCHK(hipEventRecord(r.g_done, c->aux));
     r.g_pending = true;
+    c->last_out = c->ext_blob ? reinterpret_cast<adsb_frame *>(static_cast<char *>(c->ext_blob) + 32) : r.out;
+    c->last_cap = c->ext_blob ? (uint32_t)std::min<size_t>(c->ext_frames, c->cfg.max_out) : (uint32_t)c->cfg.max_out;
     c->last = i & 1u;
     c->launch_idx = i + 1u;
     if (ev && c->last_tiles) c->ev_count++;
@@ -345,7 +354,7 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
     }
     HIPCHK(hipMemcpyAsync(c->out_start, start.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
     uint32_t limit = 0;
-    while (limit < n && start[limit] < (uint32_t)c->cfg.max_out) ++limit;
+    while (limit < n && start[limit] < c->last_cap) ++limit;
     uint32_t t0 = 0;
     int rc = ADSB_OK;
     while (t0 < limit && rc == ADSB_OK) {
@@ -404,7 +413,7 @@ extern "C" int adsb_fetch(adsb_ctx *c, adsb_frame *out, size_t max_out, size_t *
     uint32_t fl = c->hdr_host->flags;
     if (n > max_out) { n = max_out; fl |= ADSB_FLAG_TRUNCATED; }
     adsb_ctx::ResultSet &r = c->rs[c->last];
-    if (n) HIPCHK(hipMemcpyAsync(out, r.out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, c->aux));
+    if (n) HIPCHK(hipMemcpyAsync(out, c->last_out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, c->aux));
     std::vector<uint64_t> cc;
     if (per_channel_counts) {
         HIPCHK(hipMemcpyAsync(per_channel_counts, r.chan_counts, sizeof(uint64_t) * c->last_channels,
@@ -428,8 +437,18 @@ extern "C" int adsb_fetch(adsb_ctx *c, adsb_frame *out, size_t max_out, size_t *
 extern "C" int adsb_result_device(adsb_ctx *c, const adsb_frame **frames_dev, const void **header_dev)
 {
     if (!c) return ADSB_E_ARG;
-    if (frames_dev) *frames_dev = c->rs[c->last].out;
+    if (frames_dev) *frames_dev = c->last_out ? c->last_out : c->rs[c->last].out;
     if (header_dev) *header_dev = c->rs[c->last].hdr;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_set_result_target(adsb_ctx *c, void *blob_dev, size_t blob_bytes)
+{
+    if (!c) return ADSB_E_ARG;
+    if (!blob_dev) { c->ext_blob = nullptr; c->ext_frames = 0; return ADSB_OK; }
+    if (((uintptr_t)blob_dev & 15u) || blob_bytes < 32 + sizeof(adsb_frame)) return ADSB_E_ARG;
+    c->ext_blob = blob_dev;
+    c->ext_frames = (blob_bytes - 32) / sizeof(adsb_frame);
     return ADSB_OK;
 }
 

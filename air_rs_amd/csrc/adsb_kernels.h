@@ -85,6 +85,7 @@ struct CompactArgs {
     uint32_t tile_first, tile_count; // gather range
     uint32_t write_header;
     Header *hdr;
+    uint64_t *hdr_pub;         // optional caller-owned copy of {n_out, total_found, flags} (4 x u64)
 };
 
 // mag_mode: how v_cvt_pk_u8_f32 rounds on this device (decided once per ctx by probe_cvt):

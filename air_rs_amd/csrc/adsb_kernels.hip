@@ -672,6 +672,12 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
             a.hdr->flags = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
             a.hdr->alloc = 0;     // ready for the next launch
             a.hdr->next_tile = 0;
+            if (a.hdr_pub) {
+                a.hdr_pub[0] = total < a.max_out ? total : a.max_out;
+                a.hdr_pub[1] = total;
+                a.hdr_pub[2] = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
+                a.hdr_pub[3] = 0;
+            }
         }
     }
     const uint32_t t = a.tile_first + blockIdx.x * 4 + wave;

@@ -137,6 +137,10 @@ class AdsbDemod:
                 "adsb_result_device")
         return frames.value, hdr.value
 
+    def set_result_target(self, dev_ptr, nbytes):
+        """Next launches write [32-byte header | frames] straight into caller-owned HBM (None: reset)."""
+        L.check(self._lib.adsb_set_result_target(self._h, dev_ptr, nbytes), "adsb_set_result_target")
+
     def stream_wait_results(self, stream):
         """Make `stream` (hipStream_t as int) wait for the last launch's ordered frame list."""
         L.check(self._lib.adsb_stream_wait_results(self._h, stream), "adsb_stream_wait_results")

@@ -129,6 +129,14 @@ int adsb_fetch_counts(adsb_ctx *ctx, uint64_t *n_out, uint64_t *total_found, uin
  * the second-next adsb_demod_device_async() on this context.
  */
 int adsb_result_device(adsb_ctx *ctx, const adsb_frame **frames_dev, const void **header_dev);
+/*
+ * Redirects the ordered frame list of the following launches into caller-owned device memory laid
+ * out as [ uint64 n_out | uint64 total_found | uint64 flags | uint64 0 | adsb_frame[...] ]
+ * (16-byte aligned; capacity = (blob_bytes - 32) / 24 frames, further capped by cfg.max_out).
+ * Lets a consumer fill a multi-launch bucket in place (e.g. one RCCL gather per N launches) with
+ * no device-to-device copy.  blob_dev == NULL returns to the context's own buffers.
+ */
+int adsb_set_result_target(adsb_ctx *ctx, void *blob_dev, size_t blob_bytes);
 /* Makes `stream` (hipStream_t) wait for the results of the last launch; does not block the host. */
 int adsb_stream_wait_results(adsb_ctx *ctx, void *stream);
 

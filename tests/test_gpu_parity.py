@@ -262,3 +262,39 @@ def test_large_streaming_buffer_sampled(gpu, oracle):
         _eq(sel, want)
     del t
     torch.cuda.empty_cache()
+
+
+def test_caller_owned_result_target(gpu, oracle):
+    # adsb_set_result_target: the ordered list lands in caller memory as [32-byte header | frames]
+    import torch
+    n = 180_000
+    cfg = A.synth_default(seed=17, slot_len=600)
+    host = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, n)
+    rc, want, cnt = oracle.process_buffer(host)
+    t = torch.from_numpy(host).cuda()
+    cap = 1000
+    blob = torch.zeros(2, 32 + cap * 24, dtype=torch.uint8, device="cuda")
+    with A.AdsbDemod(max_samples=n, max_out=4096, host_staging=False) as d:
+        for k in range(2):  # two launches into two different slots, then back to the internal buffers
+            d.set_result_target(blob[k].data_ptr(), blob[k].numel())
+            d.demod_device_async(t.data_ptr(), n)
+        d.set_result_target(None, 0)
+        d.demod_device_async(t.data_ptr(), n)
+        frames, counts, total, flags = d.fetch()
+        _eq(frames, want)
+    torch.cuda.synchronize()
+    for k in range(2):
+        raw = blob[k].cpu().numpy()
+        hdr = raw[:32].view(np.uint64)
+        assert hdr[0] == cnt and hdr[1] == cnt and hdr[2] == 0
+        _eq(raw[32:32 + cnt * 24].view(A.FRAME_DTYPE), want)
+    # a target smaller than the frame count truncates and says so
+    small = torch.zeros(32 + 10 * 24, dtype=torch.uint8, device="cuda")
+    with A.AdsbDemod(max_samples=n, max_out=4096, host_staging=False) as d:
+        d.set_result_target(small.data_ptr(), small.numel())
+        d.demod_device_async(t.data_ptr(), n)
+        n_out, total, flags = d.fetch_counts()
+        assert n_out == 10 and total == cnt and flags & A.ADSB_FLAG_TRUNCATED
+    raw = small.cpu().numpy()
+    assert raw[:32].view(np.uint64)[0] == 10
+    _eq(raw[32:].view(A.FRAME_DTYPE), want[:10])
