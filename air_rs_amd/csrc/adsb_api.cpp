@@ -69,7 +69,7 @@ struct adsb_ctx {
     uint32_t last_tpc = 0, last_tiles = 0;
 
     // timing
-    bool timing = false;
+    int timing = 0;                 // 0 off; N: events on every N-th launch
     hipEvent_t ev[kTimingRing][4] = {};
     bool ev_made = false;
     uint32_t ev_count = 0;
@@ -307,7 +307,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     if (c->own_aux && r.g_pending) HIPCHK(hipStreamWaitEvent(c->stream, r.g_done, 0));
 
     hipEvent_t *ev = nullptr;
-    if (c->timing) {
+    if (c->timing && (c->launch_idx % (uint32_t)c->timing) == 0) {
         if (!c->ev_made) {
             for (auto &e : c->ev)
                 for (auto &x : e) HIPCHK(hipEventCreateWithFlags(&x, hipEventReleaseToDevice)); // no system-scope flush
@@ -481,7 +481,7 @@ extern "C" int adsb_demod(adsb_ctx *c, const void *iq, size_t n_samples, adsb_fr
 extern "C" int adsb_timing_enable(adsb_ctx *c, int on)
 {
     if (!c) return ADSB_E_ARG;
-    c->timing = on != 0;
+    c->timing = on > 0 ? on : 0;
     c->ev_count = 0;
     return ADSB_OK;
 }

@@ -146,8 +146,9 @@ class AdsbDemod:
         L.check(self._lib.adsb_stream_wait_results(self._h, stream), "adsb_stream_wait_results")
 
     # -- measurement / test helpers -------------------------------------------------------------------
-    def timing_enable(self, on=True):
-        L.check(self._lib.adsb_timing_enable(self._h, 1 if on else 0), "adsb_timing_enable")
+    def timing_enable(self, every=1):
+        """every = N > 0: attach timing events to every N-th launch; 0/False: off."""
+        L.check(self._lib.adsb_timing_enable(self._h, int(every)), "adsb_timing_enable")
 
     def timing_read(self):
         a, b, n = C.c_double(), C.c_double(), C.c_uint32()

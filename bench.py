@@ -140,7 +140,9 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    dem.timing_enable(os.environ.get("ADSB_BENCH_NO_TIMING") != "1")
+    # kernel durations are sampled on every 4th launch of the timed region (event-carrying dispatches
+    # cost ~4 us each; sampling keeps the timed loop within 1 % of an untimed one)
+    dem.timing_enable(0 if os.environ.get("ADSB_BENCH_NO_TIMING") == "1" else 4)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()

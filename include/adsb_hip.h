@@ -145,8 +145,8 @@ void *adsb_stream(adsb_ctx *ctx);
 
 /* ---- measurement / test helpers (bench.py, tests; not part of the reference's surface) ----- */
 /*
- * With timing on, every adsb_demod_device_async() records HIP events on the ctx stream around
- * the demodulation kernel and around the ordering pass (scan + gather).  adsb_timing_read()
+ * With timing on (on = N > 0), every N-th adsb_demod_device_async() attaches HIP events to the
+ * demodulation kernel's dispatch and to the ordering pass's (on the stream they run on).  adsb_timing_read()
  * waits for the stream, returns the mean milliseconds per launch of each since the last read
  * (at most the 512 most recent launches) and clears the log.
  */
