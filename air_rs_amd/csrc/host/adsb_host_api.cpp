@@ -68,7 +68,7 @@ extern "C" size_t adsb_packet_display(const uint8_t bytes[14], const char *time_
 template <typename T>
 static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_len, adsb_frame *frames,
                         size_t max_frames, size_t *n_frames, uint64_t *n_buffers, char *text,
-                        size_t text_cap, size_t *text_len)
+                        size_t text_cap, size_t *text_len, bool carry_over)
 {
     const Complex<T> *src = static_cast<const Complex<T> *>(data);
     std::vector<Complex<T>> all(src, src + n);
@@ -83,7 +83,7 @@ static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_
         playback_thread<T>(std::move(tx), std::move(d), chunk_len, false);
     });
     std::thread t2([&, rx = std::move(raw.second), tx = std::move(msgs.first)]() mutable {
-        st = process_sdr_data_thread<T>(ctx, std::move(rx), std::move(tx), &log, chunk_len);
+        st = process_sdr_data_thread<T>(ctx, std::move(rx), std::move(tx), &log, chunk_len + 240, carry_over);
     });
     std::thread t3([&, rx = std::move(msgs.second)]() mutable {
         while (auto packet = rx.recv()) printed += "\n" + packet->to_string("") + "\n"; // adsb.rs:156-158
@@ -101,19 +101,35 @@ static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_
     return st.last_error;
 }
 
+static int pipeline(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples, size_t chunk_len,
+                    adsb_frame *frames, size_t max_frames, size_t *n_frames, uint64_t *n_buffers, char *text,
+                    size_t text_cap, size_t *text_len, bool carry_over)
+{
+    if (!ctx || !data || chunk_len == 0) return ADSB_E_ARG;
+    if (sample_type == ADSB_SAMPLE_I16)
+        return run_pipeline<int16_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
+                                     text, text_cap, text_len, carry_over);
+    if (sample_type == ADSB_SAMPLE_I8)
+        return run_pipeline<int8_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
+                                    text, text_cap, text_len, carry_over);
+    return ADSB_E_ARG;
+}
+
 extern "C" int adsb_pipeline_playback(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples,
                                       size_t chunk_len, adsb_frame *frames, size_t max_frames,
                                       size_t *n_frames, uint64_t *n_buffers, char *text, size_t text_cap,
                                       size_t *text_len)
 {
-    if (!ctx || !data || chunk_len == 0) return ADSB_E_ARG;
-    if (sample_type == ADSB_SAMPLE_I16)
-        return run_pipeline<int16_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
-                                     text, text_cap, text_len);
-    if (sample_type == ADSB_SAMPLE_I8)
-        return run_pipeline<int8_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
-                                    text, text_cap, text_len);
-    return ADSB_E_ARG;
+    return pipeline(ctx, sample_type, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers, text,
+                    text_cap, text_len, false);
+}
+
+extern "C" int adsb_pipeline_playback_carry(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples,
+                                            size_t chunk_len, adsb_frame *frames, size_t max_frames,
+                                            size_t *n_frames, uint64_t *n_buffers)
+{
+    return pipeline(ctx, sample_type, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers, nullptr,
+                    0, nullptr, true);
 }
 
 extern "C" int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples)

@@ -60,16 +60,28 @@ void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>>
 template <typename T>
 Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex<T>>> rx,
                                      Sender<AdsbPacket> tx, std::vector<adsb_frame> *frames_log,
-                                     size_t max_frames)
+                                     size_t max_frames, bool carry_over)
 {
     Thread2Stats st;
     // A buffer of n samples has n-240 offsets, so max_frames >= the largest buffer never truncates
     // (the reference's channel is unbounded).
     std::vector<adsb_frame> frames(max_frames);
     uint64_t consumed = 0; // samples in earlier buffers, for the log's absolute offsets
+    std::vector<Complex<T>> tail; // carry_over only: the previous buffer's last 240 samples
     while (auto buf = rx.recv()) {
         size_t n_out = 0;
         uint32_t flags = 0;
+        const size_t carried = tail.size();
+        if (carry_over) {
+            std::vector<Complex<T>> joined;
+            joined.reserve(carried + buf->size());
+            joined.insert(joined.end(), tail.begin(), tail.end());
+            joined.insert(joined.end(), buf->begin(), buf->end());
+            const size_t keep = joined.size() < 240 ? joined.size() : 240;
+            tail.assign(joined.end() - keep, joined.end());
+            *buf = std::move(joined);
+            if (buf->size() < 240) { consumed += buf->size() - carried; continue; } // nothing decodable yet
+        }
         int rc = adsb_demod(ctx, buf->data(), buf->size(), frames.data(), frames.size(), &n_out, &flags);
         if (rc == ADSB_OK && (flags & ADSB_FLAG_TRUNCATED)) st.truncated_buffers++;
         if (rc != ADSB_OK) {
@@ -83,7 +95,7 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
         for (size_t k = 0; k < n_out; ++k) {
             if (frames_log) {
                 adsb_frame f = frames[k];
-                f.offset += consumed;
+                f.offset += consumed - carried;
                 frames_log->push_back(f);
             }
             AdsbPacket packet(std::vector<uint8_t>(frames[k].bytes, frames[k].bytes + 14)); // adsb.rs:107
@@ -95,7 +107,7 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
             st.frames++;
         }
         if (closed) return st;
-        consumed += buf->size();
+        consumed += buf->size() - carried;
     }
     tx.drop();
     return st;
@@ -103,7 +115,7 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
 
 template void playback_thread<int16_t>(Sender<IqBufI16>, IqBufI16, size_t, bool);
 template void playback_thread<int8_t>(Sender<IqBufI8>, IqBufI8, size_t, bool);
-template Thread2Stats process_sdr_data_thread<int16_t>(adsb_ctx *, Receiver<IqBufI16>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t);
-template Thread2Stats process_sdr_data_thread<int8_t>(adsb_ctx *, Receiver<IqBufI8>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t);
+template Thread2Stats process_sdr_data_thread<int16_t>(adsb_ctx *, Receiver<IqBufI16>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t, bool);
+template Thread2Stats process_sdr_data_thread<int8_t>(adsb_ctx *, Receiver<IqBufI8>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t, bool);
 
 } // namespace air_rs_amd

@@ -33,6 +33,11 @@ void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>>
 // ascending offset order; return when either channel closes; drop(tx) at the end.
 // `frames_log`, when given, also receives the raw frames with absolute offsets
 // (buffer start + offset) -- test instrumentation, not part of the reference.
+//
+// carry_over (NOT reference behaviour, off by default): the reference never looks at
+// the last 240 offsets of a buffer, so frames straddling two buffers are lost.  With
+// carry_over the last 240 samples of each buffer are prepended to the next one, which makes the
+// chunked stream decode exactly like one long buffer.
 struct Thread2Stats {
     uint64_t buffers = 0, frames = 0, truncated_buffers = 0;
     int last_error = ADSB_OK; // first non-OK code returned by the C ABI, if any
@@ -41,6 +46,6 @@ template <typename T>
 Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex<T>>> rx,
                                      Sender<AdsbPacket> tx,
                                      std::vector<adsb_frame> *frames_log = nullptr,
-                                     size_t max_frames = 65536);
+                                     size_t max_frames = 65536, bool carry_over = false);
 
 } // namespace air_rs_amd

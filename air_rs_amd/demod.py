@@ -190,6 +190,17 @@ class AdsbDemod:
         txt = text.value.decode() if want_text else None
         return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value, txt
 
+    def pipeline_playback_carry(self, data, chunk_len=20000, max_frames=1 << 20):
+        """Like pipeline_playback but thread 2 carries the last 240 samples over (not reference behaviour)."""
+        data = np.ascontiguousarray(data, dtype=self._np_dtype)
+        frames = np.zeros(max_frames, dtype=FRAME_DTYPE)
+        n_frames, n_buf = C.c_size_t(), C.c_uint64()
+        L.check(self._lib.adsb_pipeline_playback_carry(self._h, self.sample_type, data.ctypes.data, data.shape[0],
+                                                       chunk_len, frames.ctypes.data_as(C.POINTER(L.AdsbFrame)),
+                                                       max_frames, C.byref(n_frames), C.byref(n_buf)),
+                "adsb_pipeline_playback_carry")
+        return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value
+
 
 def packet_new(frame_bytes):
     """AdsbPacket::new (packet.rs:25-49) -> AdsbPacketView."""

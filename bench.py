@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=int, default=1 << 29, help="IQ samples per GPU (2 B each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-type", choices=["i8", "i16"], default="i8",
+                    help="i8 = BASELINE metric (2 B/sample); i16 = the reference's Complex<i16> (4 B/sample)")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the multi-rank frame-list gather even with one rank (testing)")
     args = ap.parse_args()
@@ -72,16 +74,20 @@ def main():
         dist = dist_mod
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n = args.samples
+    st = A.ADSB_SAMPLE_I8 if args.sample_type == "i8" else A.ADSB_SAMPLE_I16
+    bps = 2 if args.sample_type == "i8" else 4
+    n = args.samples if args.sample_type == "i8" else args.samples // 2  # same bytes per GPU
     cfg = A.synth_default()
     cfg_slot = cfg.slot_len
     own = n - A.WINDOW                      # offsets this rank owns
     first = rank * own                      # its slice of the long stream (240-sample read halo)
     cap = n // cfg_slot + 8192              # frame capacity: at most one frame per slot, + margin for noise
     stream = torch.cuda.current_stream()
-    dem = A.AdsbDemod(device=local_rank, sample_type=A.ADSB_SAMPLE_I8, max_samples=n, max_out=cap,
+    dem = A.AdsbDemod(device=local_rank, sample_type=st, max_samples=n, max_out=cap,
                       stream=stream.cuda_stream, host_staging=False)
-    iq = torch.empty(n * 2, dtype=torch.int8, device="cuda")
+    if st == A.ADSB_SAMPLE_I16:
+        cfg.amp_shift = 6
+    iq = torch.empty(n * bps, dtype=torch.int8, device="cuda")
     dem.synth_fill_device(cfg, 0, first, n, iq.data_ptr())
     torch.cuda.synchronize()
 
@@ -175,35 +181,35 @@ def main():
             assert got == int(frames_per_step), (got, frames_per_step)
         ms_per_step = dt / args.steps * 1e3
         value = world * n * args.steps / dt / 1e6
-        algo_bytes = 2.0 * n
+        algo_bytes = float(bps) * n
         achieved = algo_bytes / (demod_ms * 1e-3) / 1e9 if demod_ms > 0 else 0.0
-        ceil_ms = dem.time_read_ceiling(iq.data_ptr(), n * 2, 10)
+        ceil_ms = dem.time_read_ceiling(iq.data_ptr(), n * bps, 10)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and bps == 2 and n == 1 << 29:  # the PMC passes were taken on this exact workload
             try:
                 traffic = json.load(open(pmc)).get("demod_tiles_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "IQ Msamples/s (decoded Mode-S msgs/s alongside), 2 MSPS i8 stream",
+            "metric": f"IQ Msamples/s (decoded Mode-S msgs/s alongside), 2 MSPS {args.sample_type} stream",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "2 MSPS i8 IQ, 1 GiB synthetic buffer per GPU, fused magnitude+preamble/DF17 gate+PPM+CRC-24",
-                       "samples_per_gpu": n, "bytes_per_gpu": 2 * n, "frames_per_step": int(frames_per_step),
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8" if bps == 2 else "u16", "data": "synthetic",
+            "config": {"workload": f"2 MSPS {args.sample_type} IQ, {bps * n / 2**30:g} GiB synthetic buffer per GPU, fused magnitude+preamble/DF17 gate+PPM+CRC-24",
+                       "samples_per_gpu": n, "bytes_per_gpu": bps * n, "frames_per_step": int(frames_per_step),
                        "sharding": "single buffer" if world == 1 else f"time-sharded x{world}, 240-sample read halo, RCCL gather of frame lists",
                        "synth": {"seed": cfg.seed, "slot_len": cfg.slot_len, "noise_div": cfg.noise_div}},
             "msgs_per_s": round(frames_per_step * args.steps / dt, 1),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "adsbk::demod_tiles<i8>", "kernel_ms": round(demod_ms, 4),
+                         "kernel": f"adsbk::demod_tiles<{args.sample_type}>", "kernel_ms": round(demod_ms, 4),
                          "order_pass_ms": round(order_ms, 4), "launches_timed": n_timed,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "read_ceiling_gbps": round(2.0 * n / (ceil_ms * 1e-3) / 1e9, 1)},
+                         "read_ceiling_gbps": round(float(bps) * n / (ceil_ms * 1e-3) / 1e9, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and bps == 2:
             sample = iq.cpu().numpy().reshape(-1, 2)  # the whole buffer: ~6-10 s on one host core
             out["cpu_baseline"] = cpu_baseline(sample)
         print(json.dumps(out), flush=True)

@@ -60,6 +60,17 @@ int adsb_pipeline_playback(adsb_ctx *ctx, int sample_type, const void *data, siz
                            size_t chunk_len, adsb_frame *frames, size_t max_frames, size_t *n_frames,
                            uint64_t *n_buffers, char *text, size_t text_cap, size_t *text_len);
 
+/*
+ * The same three threads with carry-over switched on in thread 2 (NOT reference
+ * behaviour): the last 240 samples of every buffer are prepended to the next, so frames straddling
+ * two buffers -- which the reference loses (adsb.rs:95-98) -- are decoded, and the chunked stream
+ * yields exactly what one long buffer of the samples actually sent would.  The ctx must have been
+ * created for max_samples >= chunk_len + 240.
+ */
+int adsb_pipeline_playback_carry(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples,
+                                 size_t chunk_len, adsb_frame *frames, size_t max_frames,
+                                 size_t *n_frames, uint64_t *n_buffers);
+
 /* utils.rs:22-43 / 6-20.  adsb_load_c16 allocates *data with malloc (free with adsb_free). */
 int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples);
 int adsb_save_c16(const char *path, const int16_t *data, size_t n_samples);

@@ -298,3 +298,21 @@ def test_caller_owned_result_target(gpu, oracle):
     raw = small.cpu().numpy()
     assert raw[:32].view(np.uint64)[0] == 10
     _eq(raw[32:].view(A.FRAME_DTYPE), want[:10])
+
+
+def test_carry_over_mode_recovers_boundary_frames(gpu, oracle):
+    # SURVEY §8f-1 (switchable, not reference behaviour): with the last 240 samples carried into the
+    # next buffer, the chunked stream decodes exactly like one long buffer of the samples that were sent
+    cfg = A.synth_default(seed=5150, slot_len=700)
+    data = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 400_000)
+    chunk = 20000
+    sent = (len(data) - 1) // chunk * chunk  # playback_thread never sends the last buffer (adsb.rs:77)
+    with A.AdsbDemod(max_samples=chunk + 240, max_out=chunk + 240) as d:
+        plain, nb = d.pipeline_playback(data, chunk_len=chunk, want_text=False)[:2]
+        carried, nb2 = d.pipeline_playback_carry(data, chunk_len=chunk)
+    rc, whole, n = oracle.process_buffer(data[:sent])
+    _eq(carried, whole)
+    assert nb == nb2 == sent // chunk
+    assert len(carried) > len(plain)  # the reference loses the frames that straddle buffers
+    lost = set(carried["offset"].tolist()) - set(plain["offset"].tolist())
+    assert all((o % chunk) >= chunk - 240 for o in lost)
