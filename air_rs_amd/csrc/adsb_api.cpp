@@ -56,7 +56,6 @@ struct adsb_ctx {
     uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
-    uint32_t n_cu = 256;
 
     // pinned host mirrors
     adsbk::Header *hdr_host = nullptr;
@@ -203,11 +202,6 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
              hipMemsetAsync(c->grp, 0, sizeof(uint32_t) * grp_words, c->stream) == hipSuccess &&
              hipMemsetAsync(c->scratch, 0, 64, c->stream) == hipSuccess;
         if (!ok) { fail(ADSB_E_NOMEM); break; }
-        {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
-                c->n_cu = (uint32_t)prop.multiProcessorCount;
-        }
         if (hipHostMalloc((void **)&c->hdr_host, sizeof(adsbk::Header), hipHostMallocDefault) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
         uint32_t probe[4] = {0, 0, 0, 0};
         e = adsbk::probe_cvt(c->stream, c->scratch, probe);

@@ -44,9 +44,7 @@ struct Header {
     uint64_t total_found;  // frames that exist
     uint32_t flags;        // ADSB_FLAG_*
     uint32_t retry;        // internal: a needed tile lost its slots (slot store overflow)
-    unsigned long long alloc; // slot allocator (reset by the gather kernel)
-    uint32_t next_tile;    // tile ticket dispenser of the persistent demod kernel (reset likewise)
-    uint32_t pad;
+    unsigned long long alloc; // pool allocator for tiles over their quota (reset by the gather kernel)
 };
 
 // Tiles are grouped 64 x 64 so that any tile's position in the final list is a sum of at most
@@ -58,8 +56,8 @@ struct DemodArgs {
     uint64_t n_samples;        // per channel
     uint64_t channel_stride;   // samples
     uint32_t tiles_per_channel;
-    uint32_t tile_first;       // global tile id of ticket 0
-    uint32_t tile_count;       // tickets 0 .. tile_count-1
+    uint32_t tile_first;       // global tile id of blockIdx.x == 0
+    uint32_t tile_count;       // workgroups in this launch
     uint32_t count_groups;     // 1: add Seg::valid into grp1/grp2; 0: re-run of known tiles
     Seg *seg;
     adsb_frame *slots;         // [n_tiles_max * kQuota] fixed region, then the pool

@@ -296,16 +296,15 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     if (tid < 112) syn[tid] = kSyn.v[tid];
     // One tile per workgroup; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU
     // and starts the next tile as soon as one retires, which staggers the phases of co-resident
-    // workgroups: while one waits for its samples the others keep the VALU busy.  (A persistent,
-    // register-prefetching variant was measured slower: it needs 168 VGPRs, i.e. 12 waves per CU,
-    // and this kernel is VALU-issue-bound, not latency-bound -- DESIGN.md "What was tried".)
+    // workgroups: while one waits for its samples the others keep the VALU busy.  (Persistent
+    // variants -- atomic tickets, static round-robin, register prefetch of the next tile, single-wave
+    // workgroups -- all measured slower)
     {
-        const uint32_t ticket = blockIdx.x;
-        const uint32_t tile = p.tile_first + ticket;
+        const uint32_t tile = p.tile_first + blockIdx.x;
         const TilePos tp = tile_pos(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
-        if (ticket == 0 && tid == 0) p.hdr->retry = 0;
+        if (blockIdx.x == 0 && tid == 0) p.hdr->retry = 0;
         if (tid == 0) { misc[8] = 0; misc[12] = 0; } // valid-frame counter, survivor counter
 
         // ---- phase 1: raw IQ -> magnitudes in LDS ---------------------------------------------
@@ -647,8 +646,8 @@ __device__ __forceinline__ uint32_t tile_prefix(const CompactArgs &a, uint32_t t
 }
 
 // gather: one wave per tile copies its valid slots, in slot (= offset) order, to the final list.
-// Workgroup 0 also writes the header / per-channel counts and re-arms the allocator and ticket
-// dispenser; all workgroups clear the other parity's group counters for the next launch.
+// Workgroup 0 also writes the header / per-channel counts and re-arms the pool allocator; all
+// workgroups clear the other parity's group counters for the next launch.
 __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -671,7 +670,6 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
             a.hdr->n_out = total < a.max_out ? total : a.max_out;
             a.hdr->flags = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
             a.hdr->alloc = 0;     // ready for the next launch
-            a.hdr->next_tile = 0;
             if (a.hdr_pub) {
                 a.hdr_pub[0] = total < a.max_out ? total : a.max_out;
                 a.hdr_pub[1] = total;
