@@ -5,12 +5,13 @@ The product is the HIP library ``air_rs_amd/lib/libadsb_hip.so`` behind the C AB
 """
 from ._lib import (ADSB_E_ARG, ADSB_E_CAPACITY, ADSB_E_NODEVICE, ADSB_E_SHORT, ADSB_E_STATE,
                    ADSB_FLAG_TRUNCATED, ADSB_OK, ADSB_SAMPLE_I8, ADSB_SAMPLE_I16, AdsbError, load)
-from .demod import (FRAME_DTYPE, WINDOW, AdsbDemod, packet_display, packet_new,
+from .demod import (FIELDS_DTYPE, FRAME_DTYPE, WINDOW, AdsbDemod, packet_display, packet_new,
                     packet_new_from_string, synth_default, synth_fill_host, synth_slot)
 
 __all__ = [
     "ADSB_OK", "ADSB_E_SHORT", "ADSB_E_ARG", "ADSB_E_CAPACITY", "ADSB_E_NODEVICE", "ADSB_E_STATE",
     "ADSB_FLAG_TRUNCATED", "ADSB_SAMPLE_I8", "ADSB_SAMPLE_I16", "AdsbError", "load", "FRAME_DTYPE",
+    "FIELDS_DTYPE",
     "WINDOW", "AdsbDemod", "packet_display", "packet_new", "packet_new_from_string",
     "synth_default", "synth_fill_host", "synth_slot",
 ]

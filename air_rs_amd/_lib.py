@@ -42,6 +42,14 @@ class AdsbSynthCfg(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class AdsbPacketFields(C.Structure):
+    _fields_ = [("icao", C.c_uint32), ("altitude", C.c_int32), ("cpr_latitude", C.c_uint32),
+                ("cpr_longitude", C.c_uint32), ("downlink_format", C.c_uint8), ("capability", C.c_uint8),
+                ("msg_type", C.c_uint8), ("msg_kind", C.c_uint8), ("surveillance_status", C.c_uint8),
+                ("nic_supplement", C.c_uint8), ("cpr_time", C.c_uint8), ("cpr_odd", C.c_uint8),
+                ("callsign", C.c_char * 8)]
+
+
 class AdsbPacketView(C.Structure):
     _fields_ = [("packet", C.c_uint8 * 14), ("downlink_format", C.c_uint8), ("capability", C.c_uint8),
                 ("icao", C.c_uint32), ("msg_type", C.c_uint8), ("msg_kind", C.c_int32),
@@ -64,6 +72,9 @@ PROTOTYPES = {
                              _P(C.c_uint64), _P(C.c_uint32)]),
     "adsb_fetch_counts": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint32)]),
     "adsb_result_device": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p)]),
+    "adsb_decode_fields_device_async": (C.c_int, [C.c_void_p]),
+    "adsb_fetch_fields": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "adsb_fields_device": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
     "adsb_stream": (C.c_void_p, [C.c_void_p]),
     "adsb_stream_wait_results": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adsb_set_result_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -44,6 +44,7 @@ struct adsb_ctx {
     } rs[2];
     hipStream_t aux = nullptr;      // ordering pass + result copies (== stream unless ADSB_OVERLAP_ORDERING=1)
     bool own_aux = false;
+    adsb_packet_fields *fields = nullptr; // [max_out], allocated on first adsb_decode_fields_device_async
     void *ext_blob = nullptr;       // caller-owned [32-byte header | frames] target for the next launches
     size_t ext_frames = 0;          // frame capacity of ext_blob
     adsb_frame *last_out = nullptr; // where the last launch's ordered list went
@@ -122,6 +123,7 @@ extern "C" void adsb_destroy(adsb_ctx *c)
         if (r.g_done) (void)hipEventDestroy(r.g_done);
     }
     (void)hipFree(c->out_start);
+    (void)hipFree(c->fields);
     (void)hipFree(c->scratch);
     (void)hipFree(c->grp);
     if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
@@ -433,6 +435,39 @@ extern "C" int adsb_result_device(adsb_ctx *c, const adsb_frame **frames_dev, co
     if (!c) return ADSB_E_ARG;
     if (frames_dev) *frames_dev = c->last_out ? c->last_out : c->rs[c->last].out;
     if (header_dev) *header_dev = c->rs[c->last].hdr;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_decode_fields_device_async(adsb_ctx *c)
+{
+    if (!c) return ADSB_E_ARG;
+    if (!c->launched) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->fields && hipMalloc((void **)&c->fields, sizeof(adsb_packet_fields) * (size_t)c->cfg.max_out) != hipSuccess)
+        return ADSB_E_NOMEM;
+    // same stream as the ordering pass, so it sees the finished list and header
+    HIPCHK(adsbk::launch_decode_fields(c->aux, c->last_out, c->rs[c->last].hdr, c->last_cap, c->fields));
+    return ADSB_OK;
+}
+
+extern "C" int adsb_fields_device(adsb_ctx *c, const adsb_packet_fields **fields_dev)
+{
+    if (!c || !fields_dev) return ADSB_E_ARG;
+    *fields_dev = c->fields;
+    return c->fields ? ADSB_OK : ADSB_E_STATE;
+}
+
+extern "C" int adsb_fetch_fields(adsb_ctx *c, adsb_packet_fields *out, size_t max_out, size_t *n_out)
+{
+    if (!c || !n_out || (!out && max_out)) return ADSB_E_ARG;
+    if (!c->fields) return ADSB_E_STATE;
+    int rc = sync_header(c);
+    if (rc != ADSB_OK) return rc;
+    uint64_t n = std::min<uint64_t>(c->hdr_host->n_out, c->last_cap);
+    if (n > max_out) n = max_out;
+    if (n) HIPCHK(hipMemcpyAsync(out, c->fields, sizeof(adsb_packet_fields) * n, hipMemcpyDeviceToHost, c->aux));
+    HIPCHK(hipStreamSynchronize(c->aux));
+    *n_out = (size_t)n;
     return ADSB_OK;
 }
 

@@ -97,6 +97,10 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const Demo
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nullptr,
                          hipEvent_t e1 = nullptr);
 
+// field decode of an ordered frame list (count read from hdr->n_out on the device)
+hipError_t launch_decode_fields(hipStream_t s, const adsb_frame *frames, const Header *hdr, uint32_t cap,
+                                adsb_packet_fields *out);
+
 // test / measurement kernels
 hipError_t launch_magnitudes(hipStream_t s, int sample_type, int mag_mode, const void *iq,
                              size_t n, uint16_t *out);

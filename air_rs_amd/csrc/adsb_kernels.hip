@@ -717,6 +717,66 @@ hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0, hip
     return hipGetLastError();
 }
 
+// ---- field decode (what AdsbPacket::new computes, src/adsb/packet.rs:25-49) -----------------------
+// One thread per frame; 32-byte records.  Integer bit-field work, bound by the 24 + 32 bytes moved
+// per frame (a few MB per launch): a latency-bound epilogue, not a hot kernel.
+__constant__ char kIcaoCharset[65] = "#ABCDEFGHIJKLMNOPQRSTUVWXYZ#####_###############0123456789######"; // msgs.rs:172-177
+
+__global__ __launch_bounds__(256) void decode_fields_kernel(const adsb_frame *frames, const Header *hdr,
+                                                           uint32_t cap, adsb_packet_fields *out)
+{
+    const uint64_t n64 = hdr->n_out;
+    const uint32_t n = n64 < cap ? (uint32_t)n64 : cap;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(frames + i); // bytes[] start at byte 8
+    uint8_t b[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t v = w[2 + k];
+        b[4 * k] = v & 0xFF; b[4 * k + 1] = (v >> 8) & 0xFF; b[4 * k + 2] = (v >> 16) & 0xFF; b[4 * k + 3] = v >> 24;
+    }
+    adsb_packet_fields f;
+    f.icao = ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+    f.downlink_format = b[0] >> 3;
+    f.capability = b[0] & 5;          // sic: the reference masks with 5 (packet.rs:27)
+    f.msg_type = b[4] >> 3;
+    f.altitude = 0; f.cpr_latitude = 0; f.cpr_longitude = 0;
+    f.surveillance_status = 0; f.nic_supplement = 0; f.cpr_time = 0; f.cpr_odd = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f.callsign[k] = 0;
+    const uint8_t *m = b + 4;         // the 7-byte ME field, packet[4..11]
+    if (f.msg_type >= 1 && f.msg_type <= 4) {           // msgs.rs:210-212
+        f.msg_kind = 0;
+        unsigned long long bits = 0;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) bits = (bits << 8) | m[k];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f.callsign[c] = kIcaoCharset[(bits >> (42 - 6 * c)) & 0x3F];
+    } else if (f.msg_type >= 9 && f.msg_type <= 18) {   // msgs.rs:122-124
+        f.msg_kind = 1;
+        const int code = ((int)(m[1] >> 1) << 4) | (m[2] >> 4);
+        f.altitude = code * ((m[1] & 1) ? 25 : 100) - 1000;
+        f.surveillance_status = (m[0] >> 1) & 3;
+        f.nic_supplement = m[0] & 1;
+        f.cpr_time = (m[2] >> 3) & 1;
+        f.cpr_odd = (m[2] >> 2) & 1;
+        f.cpr_latitude = ((uint32_t)(m[2] & 3) << 15) | ((uint32_t)m[3] << 7) | (m[4] >> 1);
+        f.cpr_longitude = ((uint32_t)(m[4] & 1) << 16) | ((uint32_t)m[5] << 8) | m[6];
+    } else {
+        f.msg_kind = 2;
+    }
+    out[i] = f;
+}
+
+hipError_t launch_decode_fields(hipStream_t s, const adsb_frame *frames, const Header *hdr, uint32_t cap,
+                                adsb_packet_fields *out)
+{
+    if (cap == 0) return hipSuccess;
+    hipLaunchKernelGGL(decode_fields_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, frames, hdr, cap, out);
+    return hipGetLastError();
+}
+
 // ---- test / measurement kernels -----------------------------------------------------------------
 template <int ST, int MAGMODE>
 __global__ void magnitudes_kernel(const void *iq, size_t n, uint16_t *out)

@@ -14,6 +14,12 @@ FRAME_DTYPE = np.dtype([("offset", "<u8"), ("bytes", "u1", (14,)), ("status", "u
                         ("fixed_bit", "u1")])
 assert FRAME_DTYPE.itemsize == C.sizeof(L.AdsbFrame) == 24
 
+FIELDS_DTYPE = np.dtype([("icao", "<u4"), ("altitude", "<i4"), ("cpr_latitude", "<u4"), ("cpr_longitude", "<u4"),
+                         ("downlink_format", "u1"), ("capability", "u1"), ("msg_type", "u1"), ("msg_kind", "u1"),
+                         ("surveillance_status", "u1"), ("nic_supplement", "u1"), ("cpr_time", "u1"),
+                         ("cpr_odd", "u1"), ("callsign", "S8")])
+assert FIELDS_DTYPE.itemsize == C.sizeof(L.AdsbPacketFields) == 32
+
 WINDOW = 240  # 16 preamble + 112*2 samples (reference src/adsb.rs:98)
 
 
@@ -136,6 +142,15 @@ class AdsbDemod:
         L.check(self._lib.adsb_result_device(self._h, C.byref(frames), C.byref(hdr)),
                 "adsb_result_device")
         return frames.value, hdr.value
+
+    def decode_fields(self, max_out=None):
+        """On-device AdsbPacket field decode of the last launch's frames -> structured array."""
+        L.check(self._lib.adsb_decode_fields_device_async(self._h), "adsb_decode_fields_device_async")
+        cap = self.max_out if max_out is None else max_out
+        out = np.zeros(max(cap, 1), dtype=FIELDS_DTYPE)
+        n = C.c_size_t()
+        L.check(self._lib.adsb_fetch_fields(self._h, out.ctypes.data, cap, C.byref(n)), "adsb_fetch_fields")
+        return out[:n.value].copy()
 
     def set_result_target(self, dev_ptr, nbytes):
         """Next launches write [32-byte header | frames] straight into caller-owned HBM (None: reset)."""

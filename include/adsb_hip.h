@@ -140,6 +140,34 @@ int adsb_set_result_target(adsb_ctx *ctx, void *blob_dev, size_t blob_bytes);
 /* Makes `stream` (hipStream_t) wait for the results of the last launch; does not block the host. */
 int adsb_stream_wait_results(adsb_ctx *ctx, void *stream);
 
+/*
+ * On-device field decode of the last launch's frame list: what AdsbPacket::new
+ * computes per frame (src/adsb/packet.rs:25-49, src/adsb/msgs.rs:70-102,150-201), as one 32-byte
+ * record per frame, in frame order.  Lets the host wrapper only wrap when output volumes are large.
+ */
+typedef struct adsb_packet_fields {
+    uint32_t icao;                /* packet.rs:28 */
+    int32_t  altitude;            /* AircraftPosition (msgs.rs:70-75), feet; 0 otherwise */
+    uint32_t cpr_latitude;        /* msgs.rs:84-86 */
+    uint32_t cpr_longitude;       /* msgs.rs:87-89 */
+    uint8_t  downlink_format;     /* packet.rs:26 */
+    uint8_t  capability;          /* packet.rs:27 (mask 5, as in the reference) */
+    uint8_t  msg_type;            /* packet.rs:29 */
+    uint8_t  msg_kind;            /* 0 AircraftID, 1 AircraftPosition, 2 Uknown (msgs.rs:6-11) */
+    uint8_t  surveillance_status; /* msgs.rs:78 */
+    uint8_t  nic_supplement;      /* msgs.rs:79 */
+    uint8_t  cpr_time;            /* msgs.rs:80 */
+    uint8_t  cpr_odd;             /* msgs.rs:81-82: 1 = CprFormat::Odd */
+    char     callsign[8];         /* AircraftID (msgs.rs:180-201), not NUL terminated; zeros otherwise */
+} adsb_packet_fields;
+/* Enqueues the decode after the last launch (ctx stream); needs cfg.max_out records of ctx memory
+ * (allocated on first use). */
+int adsb_decode_fields_device_async(adsb_ctx *ctx);
+/* Waits and copies the records to the host; *n_out = number of frames decoded. */
+int adsb_fetch_fields(adsb_ctx *ctx, adsb_packet_fields *out, size_t max_out, size_t *n_out);
+/* Device pointer to the records (valid until the next decode on this ctx); does not synchronise. */
+int adsb_fields_device(adsb_ctx *ctx, const adsb_packet_fields **fields_dev);
+
 /* The stream the ctx enqueues on (hipStream_t as void*). */
 void *adsb_stream(adsb_ctx *ctx);
 

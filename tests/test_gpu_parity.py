@@ -316,3 +316,38 @@ def test_carry_over_mode_recovers_boundary_frames(gpu, oracle):
     assert len(carried) > len(plain)  # the reference loses the frames that straddle buffers
     lost = set(carried["offset"].tolist()) - set(plain["offset"].tolist())
     assert all((o % chunk) >= chunk - 240 for o in lost)
+
+
+def test_on_device_field_decode(gpu, oracle):
+    # AdsbPacket::new's field split on the GPU == the host mirror == the oracle, per frame
+    cfg = A.synth_default(seed=808, slot_len=500)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 600_000)
+    with A.AdsbDemod(max_samples=len(iq), max_out=1 << 14) as d:
+        frames, flags = d.demod(iq)
+        fields = d.decode_fields()
+    assert len(fields) == len(frames) > 800
+    kinds = set()
+    for f, g in zip(frames, fields):
+        o = oracle.packet_new(bytes(f["bytes"]))
+        kinds.add(o.msg_kind)
+        assert (g["icao"], g["downlink_format"], g["capability"], g["msg_type"], g["msg_kind"]) == \
+               (o.icao, o.downlink_format, o.capability, o.msg_type, o.msg_kind)
+        assert (g["altitude"], g["cpr_latitude"], g["cpr_longitude"], g["surveillance_status"], g["nic_supplement"],
+                g["cpr_time"], g["cpr_odd"]) == (o.altitude, o.cpr_latitude, o.cpr_longitude, o.surveillance_status,
+                                                 o.nic_supplement, o.cpr_time, o.cpr_odd)
+        assert g["callsign"] == o.callsign
+    assert kinds == {0, 1, 2}
+    # the reference's own whole-frame vectors, modulated, through the whole GPU path
+    import json, os
+    kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))["frames"]
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_frames_i8.npz"))
+    with A.AdsbDemod(max_samples=len(z["iq"]), max_out=64) as d:
+        frames, _ = d.demod(z["iq"])
+        fields = d.decode_fields()
+    for k, g in zip(kats, fields):
+        assert f"{g['icao']:06X}" == k["icao"]
+        for name in ("altitude", "cpr_latitude", "cpr_longitude", "msg_type", "capability", "downlink_format"):
+            if name in k:
+                assert g[name] == k[name], name
+        if "callsign" in k:
+            assert g["callsign"].decode() == k["callsign"]
