@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 const bool pb = (hi >> 16) >= (lo >> 16);
                 // wave-uniform test (a scalar branch, no exec juggling): the block below is entered by
                 // the whole wave when any lane passes; its effects are masked by pa/pb anyway
-                if (__builtin_amdgcn_ballot_w64(pa | pb) != 0) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa | pb) != 0, 0)) {
                     // DF17 part of the gate (demod.rs:45-54)
                     const uint32_t dh = pkmin3<ST>(pkmin3<ST>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
                     const uint32_t dl = pkmax3<ST>(pkmax3<ST>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
