@@ -5,13 +5,13 @@ Workload (BASELINE.json configs[1]): 2 MSPS-format i8 IQ, a 1 GiB synthetic buff
 in HBM before the timed region; one step = one pass of the fused magnitude + preamble/DF17 gate + PPM
 slice + CRC-24 (+ ordering pass) over that buffer.  With N > 1 ranks the stream is time-sharded: rank
 g owns offsets [g*(n-240), (g+1)*(n-240)) of one long stream and generates its own slice plus the
-240-sample read halo (no input exchange); every step ends with an RCCL gather of the decoded frame
-lists to rank 0, overlapped with the next step's kernel.  Weak scaling: per-GPU work is fixed.
+240-sample read halo (no input exchange); every launch writes its ordered frame list into a slot of an
+8-launch bucket and one RCCL gather per bucket moves the lists to rank 0 from a side stream, overlapped
+with the next bucket's kernels.  Weak scaling: per-GPU work is fixed.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
