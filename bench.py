@@ -146,9 +146,10 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    # kernel durations are sampled on every 4th launch of the timed region (event-carrying dispatches
-    # cost ~4 us each; sampling keeps the timed loop within 1 % of an untimed one)
-    dem.timing_enable(0 if os.environ.get("ADSB_BENCH_NO_TIMING") == "1" else 4)
+    # kernel durations are sampled on every 4th launch of the timed region (every launch for very short
+    # runs): event-carrying dispatches cost a few us each; sampling keeps the loop within 1 % of untimed
+    every = 4 if args.steps >= 16 else (2 if args.steps >= 4 else 1)
+    dem.timing_enable(0 if os.environ.get("ADSB_BENCH_NO_TIMING") == "1" else every)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
