@@ -18,6 +18,10 @@
 using adsbk::kTile;
 using adsbk::kWindow;
 
+#ifndef ADSB_DEFAULT_STREAM
+#define ADSB_DEFAULT_STREAM 0
+#endif
+
 namespace {
 constexpr int kTimingRing = 512;
 }
@@ -55,6 +59,9 @@ struct adsb_ctx {
     uint32_t *grp = nullptr;        // three sets x (grp1[n_grp1] | grp2[n_grp2]) valid-frame counters
     uint32_t n_grp1 = 0, n_grp2 = 0;
     uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
+    uint8_t *lut = nullptr;         // i8 streaming kernel: 64 KB floor(sqrt(I^2+Q^2)) table (swizzled index)
+    unsigned long long *stamps = nullptr; // 16 cycle counters (diagnostic builds of the streaming kernel)
+    uint32_t stream_grid = 0;       // persistent workgroups of the streaming kernel (= CUs); 0: tile kernel
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
 
@@ -125,6 +132,8 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     (void)hipFree(c->out_start);
     (void)hipFree(c->fields);
     (void)hipFree(c->scratch);
+    (void)hipFree(c->lut);
+    (void)hipFree(c->stamps);
     (void)hipFree(c->grp);
     if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
@@ -214,6 +223,27 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         else if (probe[1] == want) c->mag_mode = 1;
         else c->mag_mode = 2;
         if (const char *force = getenv("ADSB_FORCE_MAG_MODE")) c->mag_mode = atoi(force) % 3;
+        // Two tile kernels exist for i8 input: one workgroup per tile (demod_tiles, also used for i16) and
+        // the streaming kernel (one persistent workgroup per CU, table-lookup magnitudes).  ADSB_KERNEL =
+        // "tiles" | "stream" picks one at adsb_create; the default is the faster one as measured on MI355X
+        // (DESIGN.md section 5).
+        const char *kern = getenv("ADSB_KERNEL");
+        const bool stream_default = ADSB_DEFAULT_STREAM != 0;
+        const bool want_stream = cfg->sample_type == ADSB_SAMPLE_I8 &&
+                                 (kern ? strcmp(kern, "stream") == 0 : stream_default);
+        if (want_stream) {
+            int n_cu = 0;
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) {
+                fail(ADSB_E_NODEVICE);
+                break;
+            }
+            if (hipMalloc((void **)&c->lut, 65536) != hipSuccess || hipMalloc((void **)&c->stamps, 128) != hipSuccess ||
+                hipMemsetAsync(c->stamps, 0, 128, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
+            e = adsbk::launch_build_lut(c->stream, c->lut);
+            if (e != hipSuccess) { fail((int)e); break; }
+            c->stream_grid = (uint32_t)n_cu;
+            if (const char *g = getenv("ADSB_STREAM_GRID")) { int v = atoi(g); if (v > 0) c->stream_grid = (uint32_t)v; }
+        }
     } while (0);
     if (rc != ADSB_OK) { adsb_destroy(c); return rc; }
     *out_ctx = c;
@@ -222,6 +252,27 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
 
 extern "C" void *adsb_stream(adsb_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
+extern "C" int adsb_debug_kernel(adsb_ctx *c) { return c ? (c->stream_grid ? 1 : 0) : ADSB_E_ARG; }
+
+extern "C" int adsb_debug_stamps(adsb_ctx *c, uint64_t out16[16])
+{
+    if (!c || !out16) return ADSB_E_ARG;
+    if (!c->stamps) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out16, c->stamps, 128, hipMemcpyDeviceToHost));
+    return ADSB_OK;
+}
+
+extern "C" int adsb_debug_lut(adsb_ctx *c, uint8_t *table_host65536)
+{
+    if (!c || !table_host65536) return ADSB_E_ARG;
+    if (!c->lut) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpyAsync(table_host65536, c->lut, 65536, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ADSB_OK;
+}
 
 static uint32_t *grp1_of(adsb_ctx *c, uint32_t set) { return c->grp + (size_t)set * (c->n_grp1 + c->n_grp2); }
 static uint32_t *grp2_of(adsb_ctx *c, uint32_t set) { return grp1_of(c, set) + c->n_grp1; }
@@ -244,6 +295,9 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.hdr = r.hdr;
     a.grp1 = grp1_of(c, grp_set);
     a.grp2 = grp2_of(c, grp_set);
+    a.lut = c->lut;
+    a.stream_grid = c->stream_grid;
+    a.stamps = c->stamps;
     return a;
 }
 

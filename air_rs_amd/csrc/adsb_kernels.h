@@ -65,6 +65,11 @@ struct DemodArgs {
     uint32_t cap_slots;        // pool capacity
     Header *hdr;
     uint32_t *grp1, *grp2;     // this launch's parity
+    // streaming kernel (i8 only): the 64 KB floor(sqrt(I^2+Q^2)) table and the persistent grid size
+    // (number of CUs); stream_grid == 0 selects the one-workgroup-per-tile kernel
+    const uint8_t *lut;
+    uint32_t stream_grid;
+    unsigned long long *stamps; // diagnostic builds (-DADSB_STAMPS=1) only: 16 cycle counters of workgroup 0
 };
 
 struct CompactArgs {
@@ -96,6 +101,9 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const Demo
                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nullptr,
                          hipEvent_t e1 = nullptr);
+
+// 64 KB magnitude table of the streaming kernel (built once per context)
+hipError_t launch_build_lut(hipStream_t s, uint8_t *lut_dev);
 
 // field decode of an ordered frame list (count read from hdr->n_out on the device)
 hipError_t launch_decode_fields(hipStream_t s, const adsb_frame *frames, const Header *hdr, uint32_t cap,

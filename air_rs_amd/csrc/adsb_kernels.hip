@@ -258,14 +258,189 @@ __device__ __forceinline__ TilePos tile_pos(const DemodArgs &p, uint32_t tile)
 // Bounds-checked descriptor over one tile's samples (+halo): reads past the channel end return 0,
 // so ragged tails need no branches.  `tile` must be wave-uniform.
 template <int BPS>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, const TilePos &t)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, const TilePos &t, bool live = true)
 {
     const char *base = (const char *)p.iq + ((uint64_t)t.ch * p.channel_stride + t.sample0) * BPS;
     const uint64_t remain = (p.n_samples - t.sample0) * BPS; // bytes to the end of this channel
     const uint32_t nrec = remain > (uint64_t)(kMag * BPS) ? (uint32_t)(kMag * BPS) : (uint32_t)remain;
-    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)nrec, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? (int)nrec : 0, 0x00020000);
 }
 
+#ifndef ADSB_ABL_NOCMP
+#define ADSB_ABL_NOCMP 0 // measurement only (wrong results): gate without compares and branches
+#endif
+#ifndef ADSB_GATE_GROUP
+#define ADSB_GATE_GROUP 1 // steps per wave-uniform test in demod_tiles (see gate_phase)
+#endif
+
+// ---- the gate (phase 2 of both tile kernels) --------------------------------------------------
+// Preamble + DF17 ordering test (demod.rs:17-57) for the 2 x kRun offsets this lane owns:
+// run A = offsets [tid*RUN, +RUN), run B = [(tid+NT)*RUN, +RUN) of the tile whose magnitudes
+// are in `mag`.  Survivors are OR-ed into the lane's words of the LDS bitmap `cand` and appended,
+// unordered, to `list` (their number is added to *count).  No barriers inside (except what `hook`, called
+// before step HOOK_AT, does); `tid` < NT; 2 NT RUN = kTile.
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+template <int ST, int GROUP, int RUN, int NT, int HOOK_AT = -1, class HOOK = NoHook>
+__device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, uint32_t *cand, uint16_t *list,
+                                           uint32_t *count, const uint32_t tid, const uint32_t n_valid,
+                                           HOOK hook = HOOK())
+{
+    static_assert(RUN % GROUP == 0 && (RUN == 32 || RUN == 64), "steps are taken GROUP at a time; 1 or 2 bitmap words per run");
+    constexpr int WPR = RUN / 32; // bitmap words per run
+    constexpr int SPG = 16 / (int)sizeof(typename MagT<ST>::type); // magnitudes per 16-byte LDS granule
+    // Survivor bitmap: WPR words per run (offset 32 w + b of the tile is bit b of word w), owned by this
+    // lane.  The rare path ORs bits straight into LDS so the unrolled steps carry no mask registers.
+    uint32_t *candA = cand + WPR * tid, *candB = cand + WPR * (tid + NT);
+#pragma unroll
+    for (int k = 0; k < WPR; ++k) candA[k] = candB[k] = 0u;
+    // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
+    const uint32_t sa = tid * RUN, sb = (tid + NT) * RUN;
+    const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
+    constexpr int kGran = (RUN + 26 + SPG - 1) / SPG + 1; // granules a run may touch
+    const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * RUN);
+    const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + NT) * RUN);
+    uint32_t ra[kGran * 4], rb[kGran * 4];
+    constexpr int kAhead = 48 / SPG; // granules resident ahead of the current block
+#pragma unroll
+    for (int g = 0; g < kAhead; ++g) {
+        u32x4 a = ga[g], b = gb[g];
+        ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
+        rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
+    }
+
+    // Sliding state shared by neighbouring offsets (all indices are compile-time after
+    // unrolling): N[j] sample pair, H2[j] = min(N[j], N[j+2]), W3[j] = max(N[j..j+2]).
+    // Sliding state shared by neighbouring offsets (all indices are compile-time after
+    // unrolling).  With F[j] = max N[j + {0,2,3,4,5}] the twelve low slots of offset o are
+    // F[o+1] u F[o+8] u {o+13,14,15}: one new W3, one new F and one 3-input max per offset.
+    //   N[j]  sample pair             H2[j] = min(N[j], N[j+2])
+    //   W3[j] = max(N[j..j+2])        F[j]  = max(N[j], W3[j+2], N[j+5])
+    uint32_t N[RUN + 26], H2[RUN + 8], W3[RUN + 16], F[RUN + 9];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) N[k] = pair_at<ST>(ra, rb, k);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
+#pragma unroll
+    for (int j = 3; j < 13; ++j) W3[j] = pkmax3<ST>(N[j], N[j + 1], N[j + 2]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) F[j] = pkmax3<ST>(N[j], W3[j + 2], N[j + 5]);
+
+    // GROUP consecutive steps share one wave-uniform test: their 8 x GROUP min/max instructions form one
+    // basic block (independent chains the scheduler can interleave) and the common path takes one
+    // scalar branch per GROUP steps.  GROUP = 1 is what the many-waves-per-SIMD tile kernel uses; the
+    // streaming kernel, whose gate waves are alone on their SIMD's VALU, needs the larger blocks.
+#if ADSB_ABL_NOCMP
+    uint32_t abl_acc = 0;
+#endif
+#pragma unroll
+    for (int o0 = 0; o0 < RUN; o0 += GROUP) {
+        if (o0 == HOOK_AT) hook(); // the streaming kernel places a workgroup barrier inside the gate
+        bool pa[GROUP], pb[GROUP];
+        bool any = false; // per lane; the wave-wide OR is one ballot below (an s_or chain of the compare masks)
+#pragma unroll
+        for (int gi = 0; gi < GROUP; ++gi) {
+            const int o = o0 + gi;
+            if (o % SPG == 0) { // keep 48 samples resident ahead of the block that starts here
+                const int g = o / SPG + kAhead;
+                if (g * SPG < RUN + 26) {
+                    u32x4 a = ga[g], b = gb[g];
+                    ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
+                    rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
+                }
+            }
+            // pairs are unpacked 26 samples ahead so the (rare) DF17 check below finds its ten
+            // samples already in registers
+            N[o + 25] = pair_at<ST>(ra, rb, o + 25);
+            W3[o + 13] = pkmax3<ST>(N[o + 13], N[o + 14], N[o + 15]);
+            F[o + 8] = pkmax3<ST>(N[o + 8], W3[o + 10], N[o + 13]);           // lows 8,10,11,12,13
+            const uint32_t lo = pkmax3<ST>(F[o + 1], F[o + 8], W3[o + 13]);   // + 1,3,4,5,6 + 13,14,15
+            H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
+            const uint32_t hi = pkmin(H2[o], H2[o + 7]);                      // highs 0,2,7,9
+#if ADSB_ABL_NOCMP
+            abl_acc ^= hi ^ lo; // measurement only: keeps the min/max chain alive without compares/branches
+            pa[gi] = pb[gi] = false;
+#else
+            pa[gi] = (uint16_t)hi >= (uint16_t)lo;
+            pb[gi] = (hi >> 16) >= (lo >> 16);
+            any |= pa[gi] | pb[gi];
+#endif
+        }
+        // wave-uniform test (a scalar branch, no exec juggling): the block below is entered by
+        // the whole wave when any lane passes; its effects are masked by pa/pb anyway
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+#pragma unroll
+            for (int gi = 0; gi < GROUP; ++gi) {
+                const int o = o0 + gi;
+                if (GROUP == 1 || __builtin_amdgcn_ballot_w64(pa[gi] | pb[gi]) != 0) {
+                    // DF17 part of the gate (demod.rs:45-54)
+                    const uint32_t dh = pkmin3<ST>(pkmin3<ST>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
+                    const uint32_t dl = pkmax3<ST>(pkmax3<ST>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
+                    const bool da = (uint16_t)dh >= (uint16_t)dl;
+                    const bool db = (dh >> 16) >= (dl >> 16);
+                    const uint32_t bit = 1u << (o & 31);
+                    if (pa[gi] & da & ((uint32_t)o < va)) atomicOr(candA + (o >> 5), bit);
+                    if (pb[gi] & db & ((uint32_t)o < vb)) atomicOr(candB + (o >> 5), bit);
+                }
+            }
+        }
+    }
+#if ADSB_ABL_NOCMP
+    if (abl_acc == 0x12345678u) atomicOr(candA, 1u);
+#endif
+    uint32_t words[2 * WPR];
+    uint32_t nz = 0, c = 0;
+#pragma unroll
+    for (int k = 0; k < WPR; ++k) {
+        words[k] = candA[k];
+        words[WPR + k] = candB[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * WPR; ++k) {
+        nz |= words[k];
+        c += __builtin_popcount(words[k]);
+    }
+    // Survivors are rare (a handful per tile): the few lanes that have any append their offsets,
+    // unordered, to the list (ordering happens later).  The bitmap above is only read if there
+    // turn out to be more than kSparseCap.
+    if (nz) {
+        uint32_t pos = atomicAdd(count, c);
+#pragma unroll
+        for (int k = 0; k < 2 * WPR; ++k) {
+            uint32_t bits = words[k];
+            const uint32_t base = (k < WPR ? sa : sb) + (k % WPR) * 32;
+            while (bits) {
+                const uint32_t b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (pos < (uint32_t)kSparseCap) list[pos] = (uint16_t)(base + b);
+                ++pos;
+            }
+        }
+    }
+}
+
+// The same descriptor as four dwords (for inline asm): base, base_hi (stride 0), num_records, flags.
+template <int BPS>
+__device__ __forceinline__ u32x4 tile_rsrc_words(const DemodArgs &p, const TilePos &t, bool live)
+{
+    const uint64_t base = (uint64_t)(uintptr_t)((const char *)p.iq + ((uint64_t)t.ch * p.channel_stride + t.sample0) * BPS);
+    const uint64_t remain = (p.n_samples - t.sample0) * BPS;
+    const uint32_t nrec = remain > (uint64_t)(kMag * BPS) ? (uint32_t)(kMag * BPS) : (uint32_t)remain;
+    u32x4 w;
+    w.x = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    w.y = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xFFFFu);
+    w.z = __builtin_amdgcn_readfirstlane(live ? nrec : 0u);
+    w.w = 0x00020000u;
+    return w;
+}
+
+// Cache policy of the streaming IQ loads: 2 = nt (read once, do not keep): measured 3 % faster than the
+// default policy on the 1 GiB buffer (0.233 vs 0.241 ms).
+#ifndef ADSB_LOAD_AUX
+#define ADSB_LOAD_AUX 2
+#endif
 constexpr int kRawIters = (kMag + kThreads * 8 - 1) / (kThreads * 8); // 17 x 16 B per lane (i8)
 
 #ifndef ADSB_WAVES_PER_SIMD
@@ -317,7 +492,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
 #pragma unroll
                 for (int it = 0; it < kRawIters; ++it)
                     if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag)
-                        raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, 0);
+                        raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
 #pragma unroll
                 for (int it = 0; it < kRawIters; ++it) {
                     if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag) {
@@ -342,101 +517,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         __syncthreads();
 
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
-        // Run A = offsets [tid*64, +64), run B = [(tid+256)*64, +64) of the tile.
-        {
-            // Survivor bitmap: two words per run (bit o of word o>>5), owned by this lane.  The rare
-            // path ORs bits straight into LDS so the 64 unrolled steps carry no mask registers.
-            uint32_t *candA = cand + 2 * tid, *candB = cand + 2 * (tid + kThreads);
-            *reinterpret_cast<uint2 *>(candA) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2 *>(candB) = make_uint2(0u, 0u);
-            // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
-            const uint32_t sa = tid * kRun, sb = (tid + kThreads) * kRun;
-            const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
-            constexpr int kGran = (kRun + 26 + SPG - 1) / SPG + 1; // granules a run may touch
-            const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * kRun);
-            const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + kThreads) * kRun);
-            uint32_t ra[kGran * 4], rb[kGran * 4];
-            constexpr int kAhead = 48 / SPG; // granules resident ahead of the current block
-#pragma unroll
-            for (int g = 0; g < kAhead; ++g) {
-                u32x4 a = ga[g], b = gb[g];
-                ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
-                rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
-            }
-
-            // Sliding state shared by neighbouring offsets (all indices are compile-time after
-            // unrolling): N[j] sample pair, H2[j] = min(N[j], N[j+2]), W3[j] = max(N[j..j+2]).
-            // Sliding state shared by neighbouring offsets (all indices are compile-time after
-            // unrolling).  With F[j] = max N[j + {0,2,3,4,5}] the twelve low slots of offset o are
-            // F[o+1] u F[o+8] u {o+13,14,15}: one new W3, one new F and one 3-input max per offset.
-            //   N[j]  sample pair             H2[j] = min(N[j], N[j+2])
-            //   W3[j] = max(N[j..j+2])        F[j]  = max(N[j], W3[j+2], N[j+5])
-            uint32_t N[kRun + 26], H2[kRun + 8], W3[kRun + 16], F[kRun + 9];
-#pragma unroll
-            for (int k = 0; k < 25; ++k) N[k] = pair_at<ST>(ra, rb, k);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
-#pragma unroll
-            for (int j = 3; j < 13; ++j) W3[j] = pkmax3<ST>(N[j], N[j + 1], N[j + 2]);
-#pragma unroll
-            for (int j = 1; j < 8; ++j) F[j] = pkmax3<ST>(N[j], W3[j + 2], N[j + 5]);
-
-#pragma unroll
-            for (int o = 0; o < kRun; ++o) {
-                if (o % SPG == 0) { // keep 48 samples resident ahead of the block that starts here
-                    const int g = o / SPG + kAhead;
-                    if (g * SPG < kRun + 26) {
-                        u32x4 a = ga[g], b = gb[g];
-                        ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
-                        rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
-                    }
-                }
-                // pairs are unpacked 26 samples ahead so the (rare) DF17 check below finds its ten
-                // samples already in registers
-                N[o + 25] = pair_at<ST>(ra, rb, o + 25);
-                W3[o + 13] = pkmax3<ST>(N[o + 13], N[o + 14], N[o + 15]);
-                F[o + 8] = pkmax3<ST>(N[o + 8], W3[o + 10], N[o + 13]);           // lows 8,10,11,12,13
-                const uint32_t lo = pkmax3<ST>(F[o + 1], F[o + 8], W3[o + 13]);   // + 1,3,4,5,6 + 13,14,15
-                H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
-                const uint32_t hi = pkmin(H2[o], H2[o + 7]);                      // highs 0,2,7,9
-                const bool pa = (uint16_t)hi >= (uint16_t)lo;
-                const bool pb = (hi >> 16) >= (lo >> 16);
-                // wave-uniform test (a scalar branch, no exec juggling): the block below is entered by
-                // the whole wave when any lane passes; its effects are masked by pa/pb anyway
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa | pb) != 0, 0)) {
-                    // DF17 part of the gate (demod.rs:45-54)
-                    const uint32_t dh = pkmin3<ST>(pkmin3<ST>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
-                    const uint32_t dl = pkmax3<ST>(pkmax3<ST>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
-                    const bool da = (uint16_t)dh >= (uint16_t)dl;
-                    const bool db = (dh >> 16) >= (dl >> 16);
-                    const uint32_t bit = 1u << (o & 31);
-                    if (pa & da & ((uint32_t)o < va)) atomicOr(candA + (o >> 5), bit);
-                    if (pb & db & ((uint32_t)o < vb)) atomicOr(candB + (o >> 5), bit);
-                }
-            }
-            const uint2 ma = *reinterpret_cast<const uint2 *>(candA), mb = *reinterpret_cast<const uint2 *>(candB);
-            const uint32_t mA0 = ma.x, mA1 = ma.y, mB0 = mb.x, mB1 = mb.y;
-            // Survivors are rare (a handful per tile): the few lanes that have any append their
-            // offsets, unordered, to the list; wave 0 ranks them afterwards.  The bitmap above is
-            // only read if there turn out to be more than kSparseCap.
-            if (mA0 | mA1 | mB0 | mB1) {
-                const uint32_t c = __builtin_popcount(mA0) + __builtin_popcount(mA1) +
-                                   __builtin_popcount(mB0) + __builtin_popcount(mB1);
-                uint32_t pos = atomicAdd(&misc[12], c);
-                const uint32_t words[4] = {mA0, mA1, mB0, mB1};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t bits = words[k];
-                    const uint32_t base = (k < 2 ? sa : sb) + (k & 1) * 32;
-                    while (bits) {
-                        const uint32_t b = __builtin_ctz(bits);
-                        bits &= bits - 1;
-                        if (pos < (uint32_t)kSparseCap) list[pos] = (uint16_t)(base + b);
-                        ++pos;
-                    }
-                }
-            }
-        }
+        gate_phase<ST, ADSB_GATE_GROUP, kRun, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
         __syncthreads();
 
         // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
@@ -618,10 +699,13 @@ static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &
     return hipGetLastError();
 }
 
+#include "adsb_stream_kernel.h"
+
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (a.tile_count == 0) return hipSuccess;
+    if (sample_type == ADSB_SAMPLE_I8 && a.lut && a.stream_grid) return launch_demod_stream(s, a, a.stream_grid, e0, e1);
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);
     return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count, e0, e1);
 }

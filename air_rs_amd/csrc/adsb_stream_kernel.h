@@ -1,0 +1,580 @@
+// adsb_stream_kernel.h -- the streaming form of the i8 tile kernel (included by adsb_kernels.hip inside
+// namespace adsbk; it uses that file's helpers: gate_phase, kSyn, tile_pos, tile_rsrc).
+//
+// Same function as demod_tiles<ADSB_SAMPLE_I8> (same closed form, same per-tile outputs: Seg, frame
+// slots, group counters), different mapping to the machine.  demod_tiles is VALU-issue-bound: 20 of
+// its ~54 issue cycles per 64 samples go into floor(sqrt(I^2+Q^2)) (v_dot4, v_add_f32, v_sqrt_f32,
+// v_cvt_pk_u8_f32), and a workgroup alternates between waiting for HBM and computing.  Here:
+//   * one persistent 512-thread workgroup per CU (it owns 134 KB of the CU's 160 KB LDS) walks tiles
+//     blockIdx.x, blockIdx.x + gridDim.x, ...;
+//   * the magnitude is a table lookup: an i8 IQ sample is 16 bits, so floor(sqrt(I^2+Q^2)) for every
+//     possible sample is a 64 KB byte table in LDS, indexed by the raw sample (index bits swizzled so
+//     that receiver noise spreads over all LDS banks).  Exact by construction (the table is built
+//     with integer arithmetic), no floating point anywhere on the path; the work moves from the VALU
+//     to the otherwise idle LDS pipe;
+//   * wave specialisation instead of co-resident workgroups: waves 4-7 ("lookup waves") stream the
+//     raw IQ of tile i+1 from HBM (each consumed 16-byte register is immediately re-loaded with tile
+//     i+2's data, so ~68 KB per CU are always in flight), look the magnitudes up and write them to the
+//     second of two LDS magnitude buffers, while waves 0-3 ("gate waves") run the preamble/DF17 gate
+//     and the PPM/CRC decode of tile i from the first buffer.  One gate wave and one lookup wave share
+//     each SIMD: the gate wave uses its VALU, the lookup wave the LDS and memory pipes.
+#pragma once
+
+// ablation switches for measurements (tools/gpu): results are wrong when set
+#ifndef ADSB_ABL_NOLOOKUP
+#define ADSB_ABL_NOLOOKUP 0
+#endif
+#ifndef ADSB_ABL_NOGATE
+#define ADSB_ABL_NOGATE 0
+#endif
+
+// Diagnostic build (-DADSB_STAMPS=1): workgroup 0 accumulates s_memtime deltas per segment of a round
+// (gate wave 0: slots 0-7, lookup wave 0: slots 8-11, rounds in slot 15) into DemodArgs::stamps.
+#ifndef ADSB_STAMPS
+#define ADSB_STAMPS 0
+#endif
+#if ADSB_STAMPS
+#define STAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_START()                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#define STAMP(k)                                                                              \
+    do {                                                                                      \
+        unsigned long long st_now;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        st_acc[k] += st_now - st_prev;                                                        \
+        st_prev = st_now;                                                                     \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_START() do { } while (0)
+#define STAMP(k) do { } while (0)
+#endif
+
+// Eight gate waves (two per SIMD: one wave alone issues an instruction only every ~16 cycles, the
+// VALU -> SGPR -> s_cbranch chain of every gate step being fully exposed) + four lookup waves.
+constexpr int kSGateThreads = 512;           // 8 gate waves: 2 runs of kSRun offsets per lane
+constexpr int kSRun = kTile / (2 * kSGateThreads); // 32
+#ifndef ADSB_STREAM_LOOKUP_WAVES
+#define ADSB_STREAM_LOOKUP_WAVES 8
+#endif
+constexpr int kSLookupThreads = 64 * ADSB_STREAM_LOOKUP_WAVES; // lookup waves: sweeps of 16 B (8 samples) per lane
+constexpr int kSSweep = kSLookupThreads * 8;                  // samples per sweep of all lookup waves
+constexpr int kSFull = kTile / kSSweep;                       // full sweeps per tile ...
+constexpr int kSIters = kSFull + 1;                           // ... + one sweep for the kHalo extra samples
+static_assert(kTile % kSSweep == 0 && kHalo <= kSSweep, "sweep layout");
+#define ADSB_STR2(x) #x
+#define ADSB_STR(x) ADSB_STR2(x)
+// when a sweep's quad is consumed, the kSIters - 1 loads issued after its own may still be in flight
+#if ADSB_STREAM_LOOKUP_WAVES == 8
+#define ADSB_STREAM_VMCNT 8
+#elif ADSB_STREAM_LOOKUP_WAVES == 4
+#define ADSB_STREAM_VMCNT 16
+#else
+#error "ADSB_STREAM_LOOKUP_WAVES must be 4 or 8"
+#endif
+static_assert(ADSB_STREAM_VMCNT == kSIters - 1, "wait count matches the number of sweeps");
+constexpr int kSThreads = kSGateThreads + kSLookupThreads;
+constexpr int kSGroups = kSGateThreads / 16; // 16-lane decode groups
+constexpr int kLutBytes = 65536;
+
+// Table index of a raw sample r = (Q << 8) | I (little-endian i8 pair).  The LDS bank of a byte
+// address is bits 6:2; unswizzled those are I[6:2], which take ~13 values on receiver noise.  XOR-ing
+// Q << 2 into bits 9:2 makes them I[6:2] ^ Q[4:0] (uniform on noise) and stays a bijection on 16 bits.
+// On a packed dword of two samples: x = v ^ ((v >> 6) & 0x03FC03FC).
+__host__ __device__ constexpr uint32_t lut_swizzle(uint32_t raw16)
+{
+    return raw16 ^ ((raw16 >> 6) & 0x03FCu);
+}
+
+// floor(sqrt(I^2+Q^2)) for all 65536 samples, integer arithmetic only (utils.rs:46-52 computes the same
+// value through f64 sqrt + truncation; tests/test_gpu_parity.py compares the table with the oracle).
+__global__ void build_lut_kernel(uint8_t *lut)
+{
+    const uint32_t raw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (raw >= (uint32_t)kLutBytes) return;
+    const int i = (int)(int8_t)(raw & 0xFFu), q = (int)(int8_t)(raw >> 8);
+    const uint32_t n = (uint32_t)(i * i + q * q); // <= 32768
+    uint32_t r = 0;
+    while ((r + 1u) * (r + 1u) <= n) ++r;
+    lut[lut_swizzle(raw)] = (uint8_t)r;
+}
+
+hipError_t launch_build_lut(hipStream_t s, uint8_t *lut_dev)
+{
+    hipLaunchKernelGGL(build_lut_kernel, dim3(kLutBytes / 256), dim3(256), 0, s, lut_dev);
+    return hipGetLastError();
+}
+
+#ifndef ADSB_STREAM_GATE_GROUP
+#define ADSB_STREAM_GATE_GROUP 1 // gate steps per wave-uniform test (see gate_phase; 1 measured fastest)
+#endif
+
+struct SLds {
+    static constexpr int kOffLut = 0;
+    static constexpr int kOffMag0 = kLutBytes;
+    static constexpr int kOffMag1 = kOffMag0 + kMag;
+    static constexpr int kOffCand = kOffMag1 + kMag;            // survivor bitmap, 1024 words
+    static constexpr int kOffList = kOffCand + 2 * kThreads * 8; // 2 (round parity) x kListCap x u16
+    static constexpr int kOffSyn = kOffList + 2 * kListCap * 2;
+    static constexpr int kOffStage = kOffSyn + 112 * 4;         // 2 (round parity) x kSparseCap x 24 B frame records
+    static constexpr int kOffRes = kOffStage + 2 * kSparseCap * 24; // dense path: per-group record staging
+    static constexpr int kOffMisc = kOffRes + kSGroups * 24;
+    static constexpr int kTotal = kOffMisc + 64;
+    // misc words: [0..3] dense-path partial sums, [8 + parity] valid frames of the round,
+    // [10] pool allocation of an over-quota tile (dense path), [12 + parity] gate survivors of the round
+    static constexpr int kValid = 8, kAlloc = 10, kCount = 12;
+};
+static_assert(SLds::kTotal <= 160 * 1024, "LDS budget");
+static_assert(kMag % 16 == 0 && SLds::kOffStage % 8 == 0, "alignment of the LDS regions");
+
+// Table indices of the 8 raw samples of one 16-byte load (both samples of a dword share the swizzle) ...
+__device__ __forceinline__ void lookup_indices(u32x4 v, uint32_t x[4])
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) x[d] = w[d] ^ ((w[d] >> 6) & 0x03FC03FCu);
+}
+// ... the eight byte reads ...
+__device__ __forceinline__ void lookup_reads(const unsigned char *lut, const uint32_t x[4], uint32_t m[8])
+{
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        m[2 * d] = lut[x[d] & 0xFFFFu];
+        m[2 * d + 1] = lut[x[d] >> 16];
+    }
+}
+// In-place re-load of a raw quad whose eight table indices idx[] have been extracted: one asm statement
+// with the quad and the indices as tied operands, so that (a) the quad's old value is dead afterwards --
+// hipcc would otherwise re-derive the indices from it later, keep it alive across the load and move
+// the load to another quad -- and (b) the load lands in the registers it is later consumed from.
+__device__ __forceinline__ void reload_in_place(u32x4 &quad, uint32_t idx[8], uint32_t voff, u32x4 rsrc)
+{
+    asm volatile("buffer_load_dwordx4 %0, %9, %10, 0 offen nt"
+                 : "+v"(quad), "+v"(idx[0]), "+v"(idx[1]), "+v"(idx[2]), "+v"(idx[3]), "+v"(idx[4]), "+v"(idx[5]),
+                   "+v"(idx[6]), "+v"(idx[7])
+                 : "v"(voff), "s"(rsrc));
+}
+__device__ __forceinline__ void lookup_indices8(u32x4 v, uint32_t idx[8])
+{
+    uint32_t x[4];
+    lookup_indices(v, x);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        idx[2 * d] = x[d] & 0xFFFFu;
+        idx[2 * d + 1] = x[d] >> 16;
+    }
+}
+__device__ __forceinline__ void lookup_reads8(const unsigned char *lut, const uint32_t idx[8], uint32_t m[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = lut[idx[k]];
+}
+// ... and the packing of the eight magnitudes into two dwords.
+__device__ __forceinline__ uint2 lookup_pack(const uint32_t m[8])
+{
+    const uint32_t p0 = m[0] | (m[1] << 16), p1 = m[2] | (m[3] << 16), p2 = m[4] | (m[5] << 16), p3 = m[6] | (m[7] << 16);
+    return make_uint2(__builtin_amdgcn_perm(p1, p0, 0x06040200u), __builtin_amdgcn_perm(p3, p2, 0x06040200u));
+}
+
+// XOR / sum over each row of 16 lanes (a decode group), result in every lane: four DPP steps (VALU
+// latency each) instead of four ds_bpermute round trips through the LDS.
+#define ADSB_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ uint32_t row16_xor(uint32_t v)
+{
+    v ^= ADSB_DPP(v, 0xB1);  // quad_perm [1,0,3,2]
+    v ^= ADSB_DPP(v, 0x4E);  // quad_perm [2,3,0,1]
+    v ^= ADSB_DPP(v, 0x141); // row_half_mirror
+    v ^= ADSB_DPP(v, 0x140); // row_mirror
+    return v;
+}
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v)
+{
+    v += ADSB_DPP(v, 0xB1);
+    v += ADSB_DPP(v, 0x4E);
+    v += ADSB_DPP(v, 0x141);
+    v += ADSB_DPP(v, 0x140);
+    return v;
+}
+
+// ---- role: lookup waves (the last ADSB_STREAM_LOOKUP_WAVES) ---------------------------------------------------------------------
+// Per round i: convert the raw registers (tile i+1) into the other magnitude buffer, re-loading every
+// consumed register with tile i+2's data, then take part in the round's barriers.  The barrier count
+// per round depends on how many candidates the gate found; it is re-derived here from the same LDS
+// words the gate waves use, so both roles always execute the same number of s_barrier.
+__device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned char *smem, const uint32_t tg,
+                                                   const uint32_t tile0, const uint32_t G, const uint32_t n_my)
+{
+    typedef SLds L;
+    const unsigned char *lut = smem + L::kOffLut;
+    const uint32_t *misc = reinterpret_cast<const uint32_t *>(smem + L::kOffMisc);
+    const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tg & ~63u) * 8; // first sample of this wave's sweep
+
+    // Pass r converts tile r-1 (if 1 <= r <= n_my) from the raw registers into magnitude buffer (r-1)&1
+    // and re-loads every consumed register, in place, with the same piece of tile r (if r < n_my;
+    // otherwise through an empty descriptor: zeros, no traffic).  Pass 0 and the last pass convert zeros
+    // into a buffer nobody reads: one uniform, branch-free body.  All loads are issued unconditionally:
+    // lanes past the tile's samples -- most of the last sweep, which only covers the 256-sample halo --
+    // are clipped by the descriptor and cost no traffic.
+    //
+    // The loads and their waits are inline asm.  With the builtin, every formulation tried made hipcc
+    // either drain (s_waitcnt vmcnt(0)) or rotate the 17 register quads through 68 v_mov per pass,
+    // because it cannot keep a load that is in flight across the loop's back edge in the register it
+    // will be consumed from.  Tied operands ("+v") pin each quad; the wait is explicit: when sweep `it`
+    // is consumed, the kSIters - 1 loads issued after its own (the rest of the previous pass, the start of this
+    // one) may still be in flight -> s_waitcnt vmcnt(kSIters - 1).  These waves issue no other vector memory
+    // instruction, so the count is exact.  (hipcc must not copy a quad between its load and its wait:
+    // checked in the ISA -- no v_mov touches them.)
+    u32x4 raw[kSIters];
+#pragma unroll
+    for (int it = 0; it < kSIters; ++it) raw[it] = u32x4{0u, 0u, 0u, 0u};
+
+    STAMP_DECL;
+    STAMP_START();
+    for (uint32_t r = 0; r <= n_my + 1; ++r) {
+        unsigned char *dst = smem + ((r & 1u) ? L::kOffMag0 : L::kOffMag1); // buffer (r-1)&1
+        const bool more = r < n_my;
+        const TilePos tpn = tile_pos(p, more ? tile0 + r * G : tile0);
+        const u32x4 rn = tile_rsrc_words<2>(p, tpn, more);
+        // Software pipeline: the byte reads of sweep `it` are issued before the magnitudes of sweep
+        // `it - 1` are packed and stored, so a wave always has 8-16 table reads in flight.
+        uint32_t mprev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int it = 0; it < kSIters - 1; ++it) {
+            uint32_t idx[8], m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            asm volatile("s_waitcnt vmcnt(" ADSB_STR(ADSB_STREAM_VMCNT) ")" : "+v"(raw[it]));
+            lookup_indices8(raw[it], idx);
+            reload_in_place(raw[it], idx, (uint32_t)it * (kSLookupThreads * 16) + tg * 16, rn);
+            if (!ADSB_ABL_NOLOOKUP) lookup_reads8(lut, idx, m);
+            if (it > 0 && !ADSB_ABL_NOLOOKUP)
+                *reinterpret_cast<uint2 *>(dst + (uint32_t)(it - 1) * (kSLookupThreads * 8) + tg * 8) = lookup_pack(mprev);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mprev[k] = m[k];
+            // keep the sweeps in program order (hipcc would otherwise hoist all 16 index computations,
+            // and with them the waits, to the top of the pass)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!ADSB_ABL_NOLOOKUP)
+            *reinterpret_cast<uint2 *>(dst + (uint32_t)(kSIters - 2) * (kSLookupThreads * 8) + tg * 8) = lookup_pack(mprev);
+        {
+            // the last sweep only covers the 256-sample halo: 32 lanes of the first lookup wave
+            constexpr int it = kSIters - 1;
+            uint32_t idx[8];
+            asm volatile("s_waitcnt vmcnt(" ADSB_STR(ADSB_STREAM_VMCNT) ")" : "+v"(raw[it]));
+            lookup_indices8(raw[it], idx);
+            reload_in_place(raw[it], idx, (uint32_t)it * (kSLookupThreads * 16) + tg * 16, rn);
+            if (wave_s0 == 0 && !ADSB_ABL_NOLOOKUP) { // scalar branch
+                const uint32_t s = (uint32_t)it * (kSLookupThreads * 8) + tg * 8;
+                uint32_t m[8];
+                lookup_reads8(lut, idx, m);
+                if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(dst + s) = lookup_pack(m);
+            }
+        }
+        STAMP(0); // conversion pass
+        __syncthreads(); // P1 (r = 0: table in LDS), P2 (r = 1: tile 0 converted), B1 of round r - 2
+        STAMP(1); // wait for the gate waves
+        if (r < 2) continue;
+        // mirror of the gate role's barriers for round r - 2
+        const uint32_t par = r & 1u;
+        uint32_t total = misc[L::kCount + par];
+        const bool dense = total > (uint32_t)kSparseCap;
+        if (dense) {
+            __syncthreads(); // BD
+            total = misc[0] + misc[1] + misc[2] + misc[3];
+        }
+        if (total > kQuota) __syncthreads(); // BA
+        if (dense) {
+            for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+                __syncthreads(); // BC1
+                __syncthreads(); // BC2
+            }
+        }
+        __syncthreads(); // X
+        STAMP(2); // the gate waves' decode
+    }
+    // nothing may be in flight into registers when the wave ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if ADSB_STAMPS
+    if (blockIdx.x == 0 && tg == 0 && p.stamps)
+        for (int k = 0; k < 4; ++k) p.stamps[8 + k] = st_acc[k];
+#endif
+}
+
+// ---- role: gate waves (the first eight) -----------------------------------------------------------------------
+// Per round i: preamble/DF17 gate of tile i from its magnitude buffer, then PPM slice, CRC-24 and
+// single-bit repair of the survivors.  Two barriers per round in the normal (sparse) case: B1 after the
+// gate, X after the decode; the survivor list and the counters are double-buffered by round parity so
+// that thread 0 can write the tile's record while the other waves already gate the next tile.
+__device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned char *smem, const uint32_t tid,
+                                                 const uint32_t tile0, const uint32_t G, const uint32_t n_my)
+{
+    typedef SLds L;
+    constexpr int ST = ADSB_SAMPLE_I8;
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + L::kOffCand);
+    uint16_t *lists = reinterpret_cast<uint16_t *>(smem + L::kOffList);
+    const uint32_t *syn = reinterpret_cast<const uint32_t *>(smem + L::kOffSyn);
+    unsigned char *res = smem + L::kOffRes;
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t g = tid >> 4, l = tid & 15; // kSGroups groups of 16 lanes: one candidate each, one lane per frame byte
+
+    __syncthreads(); // P1
+    __syncthreads(); // P2: tile 0's magnitudes are in buffer 0
+    STAMP_DECL;
+    STAMP_START();
+
+    // Per-tile record (Seg + group counters) of a finished round; its counters are re-armed for the round
+    // after next (same parity; barriers B1 and X of the round in between order that).
+    bool rec_pending = false;
+    uint32_t rec_tile = 0, rec_base = 0, rec_total = 0, rec_par = 0;
+    auto record = [&]() {
+        if (tid == 0 && rec_pending) {
+            const uint32_t rp = rec_par;
+            Seg e;
+            e.base = rec_base;
+            e.cand = rec_total;
+            e.valid = misc[L::kValid + rp];
+            e.pad = 0;
+            p.seg[rec_tile] = e;
+            if (e.valid && p.count_groups) {
+                atomicAdd(&p.grp1[rec_tile >> kGrpShift], e.valid);
+                atomicAdd(&p.grp2[(rec_tile >> (2 * kGrpShift)) * kGrp2Shards + ((rec_tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
+            }
+            misc[L::kValid + rp] = 0;
+            misc[L::kCount + rp] = 0;
+        }
+    };
+
+    for (uint32_t i = 0; i < n_my; ++i) {
+        const uint32_t tile = tile0 + i * G;
+        const TilePos tp = tile_pos(p, tile);
+        const uint64_t sample0 = tp.sample0;
+        const unsigned char *mag = smem + ((i & 1u) ? L::kOffMag1 : L::kOffMag0);
+        const uint32_t par = i & 1u;
+        uint16_t *list = lists + par * kListCap;
+
+        if (!ADSB_ABL_NOGATE)
+            gate_phase<ST, ADSB_STREAM_GATE_GROUP, kSRun, kSGateThreads>(mag, cand, list, &misc[L::kCount + par], tid, tp.n_valid);
+        STAMP(0); // gate
+        record(); // of the previous round
+        STAMP(6);
+        __syncthreads(); // B1: survivors listed; the lookup waves have filled the other buffer
+        STAMP(1); // wait for the lookup waves
+
+        // PPM slice + CRC-24 + single-bit repair of one candidate by a 16-lane group; the 24-byte record
+        // goes to frame slot `slot` of the tile (slots are in offset order: the gather pass relies on it).
+        auto decode = [&](const bool have, const uint32_t off, const uint32_t base_slot, const uint32_t slot) {
+            // lane l slices frame byte l: magnitudes off+16+16l .. off+16+16l+15  (demod.rs:97-101)
+            const uint32_t lb = l < 14 ? l : 13;
+            uint32_t byte = 0;
+            {
+                const uint32_t pidx = off + 16 + 16 * lb;
+                const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
+                const uint32_t sh = pidx & 3;
+                uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
+                uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                 __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1: bit = (a > b)
+                    // b - a per 16-bit half wraps (sets bit 15) exactly when a > b; no selects (v_cndmask
+                    // issues four times slower than other VALU instructions here)
+                    const u16x2 xa = __builtin_bit_cast(u16x2, w[k] & 0x00FF00FFu);
+                    const u16x2 xb = __builtin_bit_cast(u16x2, (w[k] >> 8) & 0x00FF00FFu);
+                    const uint32_t z = __builtin_bit_cast(uint32_t, (u16x2)(xb - xa)) & 0x80008000u;
+                    byte |= ((z >> (8 + 2 * k)) & 0xFFu) | (z >> (25 + 2 * k));
+                }
+            }
+            // syndrome = XOR of table entries of the set bits, over the 14 bytes
+            uint32_t s = 0;
+            const uint32_t *sy = syn + 8 * lb;
+            {
+                const int sb = (int)(l < 14 ? byte : 0u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
+            }
+            s = row16_xor(s);
+            // single-bit repair: only the 88 data bits can match (crc.rs:49-65)
+            int found = -1;
+            if (s != 0 && l < 11) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
+            }
+            const unsigned long long fm = __ballot(found >= 0);
+            const uint32_t gsh = (lane & 48u);
+            const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
+            const bool valid = have && (s == 0 || gbits != 0);
+            uint32_t status = 0xFFu, fixed = 0xFFu;
+            if (valid) {
+                status = (s == 0) ? 0u : 1u;
+                if (s != 0) {
+                    const uint32_t fl = __builtin_ctz(gbits);
+                    const int fk = __shfl(found, (int)fl, 16);
+                    fixed = 8 * fl + (uint32_t)fk;
+                    if (l == fl) byte ^= 0x80u >> fk;
+                }
+            }
+            // stage the 24-byte record, then 6 lanes store it as dwords
+            unsigned char *rec = res + g * 24;
+            if (l < 14) rec[8 + l] = (unsigned char)byte;
+            if (l == 14) rec[22] = (unsigned char)status;
+            if (l == 15) rec[23] = (unsigned char)fixed;
+            if (l == 0) {
+                const uint64_t o64 = sample0 + off;
+                reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
+                reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
+                if (valid) atomicAdd(&misc[L::kValid + par], 1u);
+            }
+            if (have && base_slot != kNoBase && l < 6) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + slot);
+                dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
+            }
+        };
+
+        uint32_t total = misc[L::kCount + par];
+        const bool dense = total > (uint32_t)kSparseCap;
+        u32x4 cw = {0, 0, 0, 0};
+        uint32_t cnt = 0, my_first = 0;
+        if (dense) {
+            // dense fallback: ordered compaction of the bitmap (1024 words; offset 32 w + b is bit b of
+            // word w) by prefix sums over the first four gate waves, four words per lane
+            uint32_t incl = 0;
+            if (wave < 4) {
+                cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
+                cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) +
+                      __builtin_popcount(cw.w);
+                incl = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    uint32_t t = __shfl_up(incl, d, 64);
+                    if ((int)lane >= d) incl += t;
+                }
+                if (lane == 63) misc[wave] = incl;
+            }
+            __syncthreads(); // BD
+            uint32_t wbase = 0;
+            total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                uint32_t t = misc[w];
+                wbase += (w < (int)wave) ? t : 0u;
+                total += t;
+            }
+            my_first = wbase + incl - cnt;
+        }
+        // Frame slots: the tile's own fixed region when the survivors fit (no atomics), otherwise one
+        // allocation from the shared pool.
+        uint32_t base_slot = tile * kQuota;
+        if (total > kQuota) {
+            if (tid == 0) {
+                const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+                misc[L::kAlloc] = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
+            }
+            __syncthreads(); // BA
+            base_slot = misc[L::kAlloc];
+        }
+        if (!dense) {
+            // The list is unordered; a candidate's slot is its rank: the number of listed offsets below
+            // its own (no separate sort step, no barrier).  total <= kSparseCap = 64 = 16 lanes x 4.
+            for (uint32_t r = 0; r < total; r += kSGroups) {
+                if (r + 4 * wave >= total) break; // none of this wave's four groups has a candidate
+                const uint32_t ci = r + g;
+                const bool have = ci < total; // uniform within the 16-lane group
+                const uint32_t off = have ? list[ci] : 0u;
+                uint32_t below = 0;
+#pragma unroll
+                for (int k = 0; k < kSparseCap / 16; ++k) {
+                    const uint32_t j = l + 16 * k;
+                    const uint32_t e = j < total ? (uint32_t)list[j] : 0xFFFFFFFFu;
+                    below += e < off ? 1u : 0u;
+                }
+                below = row16_sum(below);
+                decode(have, off, base_slot, below);
+            }
+            STAMP(4); // decode
+        } else {
+            for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+                if (cnt) {
+                    uint32_t idx = my_first;
+                    const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t bits = words[k];
+                        while (bits) {
+                            const uint32_t b = __builtin_ctz(bits);
+                            bits &= bits - 1;
+                            if (idx >= chunk && idx < chunk + kListCap)
+                                list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
+                            ++idx;
+                        }
+                    }
+                }
+                __syncthreads(); // BC1
+                const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
+                for (uint32_t r = 0; r < ncl; r += kSGroups) {
+                    if (r + 4 * wave >= ncl) break;
+                    const uint32_t ci = r + g;
+                    const bool have = ci < ncl;
+                    decode(have, have ? list[ci] : 0u, base_slot, chunk + ci);
+                }
+                __syncthreads(); // BC2
+            }
+        }
+        __syncthreads(); // X: decode done; this round's magnitude buffer, bitmap and staging are free
+        STAMP(5);
+        // the tile's record is written by thread 0 after the NEXT gate (where the gate waves wait for the
+        // lookup waves anyway), not here on the critical path
+        rec_pending = true;
+        rec_tile = tile;
+        rec_base = base_slot;
+        rec_total = total;
+        rec_par = par;
+    }
+    record();
+#if ADSB_STAMPS
+    if (blockIdx.x == 0 && tid == 0 && p.stamps) {
+        for (int k = 0; k < 8; ++k) p.stamps[k] = st_acc[k];
+        p.stamps[15] = n_my;
+    }
+#endif
+}
+
+__global__ __launch_bounds__(kSThreads, 1) void demod_stream_i8(DemodArgs p)
+{
+    typedef SLds L;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- prologue: table and constants into LDS ---------------------------------------------------
+    {
+        unsigned char *lut = smem + L::kOffLut;
+        uint32_t *syn = reinterpret_cast<uint32_t *>(smem + L::kOffSyn);
+        uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
+        for (uint32_t k = tid; k < (uint32_t)(kLutBytes / 16); k += kSThreads)
+            reinterpret_cast<u32x4 *>(lut)[k] = reinterpret_cast<const u32x4 *>(p.lut)[k];
+        if (tid < 112) syn[tid] = kSyn.v[tid];
+        if (tid < 16) misc[tid] = 0;
+        if (blockIdx.x == 0 && tid == 0) p.hdr->retry = 0;
+    }
+    const uint32_t G = gridDim.x;
+    const uint32_t n_my = (p.tile_count - blockIdx.x + G - 1) / G; // >= 1: the grid is at most tile_count
+    const uint32_t tile0 = p.tile_first + blockIdx.x;
+
+    // Two roles, two loops (a scalar branch: whole waves).  Both execute the same sequence of barriers.
+    if (wave < (uint32_t)(kSGateThreads / 64)) stream_gate_role(p, smem, tid, tile0, G, n_my);
+    else stream_lookup_role(p, smem, tid - kSGateThreads, tile0, G, n_my);
+}
+
+hipError_t launch_demod_stream(hipStream_t s, const DemodArgs &a, uint32_t n_cu, hipEvent_t e0, hipEvent_t e1)
+{
+    if (a.tile_count == 0) return hipSuccess;
+    const uint32_t grid = a.tile_count < n_cu ? a.tile_count : n_cu;
+    hipExtLaunchKernelGGL(demod_stream_i8, dim3(grid), dim3(kSThreads), 0, s, e0, e1, 0, a);
+    return hipGetLastError();
+}

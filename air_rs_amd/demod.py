@@ -99,6 +99,24 @@ class AdsbDemod:
     def mag_mode(self):
         return self._lib.adsb_debug_mag_mode(self._h)
 
+    @property
+    def kernel(self):
+        """'stream' (i8 default) or 'tiles' (i16; i8 with ADSB_KERNEL=tiles at creation)."""
+        return "stream" if self._lib.adsb_debug_kernel(self._h) == 1 else "tiles"
+
+    def stamps(self):
+        """Diagnostic builds (-DADSB_STAMPS=1): 16 shader-cycle sums of workgroup 0, last launch."""
+        out = np.zeros(16, dtype=np.uint64)
+        L.check(self._lib.adsb_debug_stamps(self._h, out.ctypes.data), "adsb_debug_stamps")
+        return out
+
+    def magnitude_table(self):
+        """The streaming kernel's 64 KB table, un-swizzled: entry (Q << 8) | I (as unsigned bytes)."""
+        raw = np.zeros(65536, dtype=np.uint8)
+        L.check(self._lib.adsb_debug_lut(self._h, raw.ctypes.data), "adsb_debug_lut")
+        r = np.arange(65536, dtype=np.uint32)
+        return raw[r ^ ((r >> 6) & 0x3FC)]
+
     # -- one received buffer (reference adsb.rs:95-116) -------------------------------------------
     def demod(self, iq, max_out=None):
         """iq: array of shape (n, 2) [I, Q] of the ctx sample dtype.  Returns (frames, flags)."""

@@ -191,6 +191,17 @@ int adsb_debug_magnitudes(adsb_ctx *ctx, const void *iq_host, size_t n_samples,
 /* How v_cvt_pk_u8_f32 was found to round on this device: 0 truncates, 1 truncates under
  * MODE.fp_round = toward-zero, 2 rounds to nearest (kernel subtracts 0.5 first). */
 int adsb_debug_mag_mode(adsb_ctx *ctx);
+/* Which tile kernel the context launches: 1 = streaming kernel (i8 default: one persistent workgroup per
+ * CU, magnitudes by table lookup), 0 = one workgroup per tile (i16; i8 when ADSB_KERNEL=tiles was set
+ * in the environment at adsb_create). */
+int adsb_debug_kernel(adsb_ctx *ctx);
+/* The streaming kernel's 64 KB magnitude table as it sits on the device: entry
+ * r ^ ((r >> 6) & 0x3FC) holds floor(sqrt(I^2+Q^2)) of the raw sample r = (Q << 8) | I (utils.rs:46-52).
+ * ADSB_E_STATE if the context does not use the streaming kernel. */
+int adsb_debug_lut(adsb_ctx *ctx, uint8_t *table_host65536);
+/* Diagnostic builds of the streaming kernel (-DADSB_STAMPS=1) only: per-segment shader-cycle sums of
+ * workgroup 0 over the last launch (zeros in a normal build). */
+int adsb_debug_stamps(adsb_ctx *ctx, uint64_t out16[16]);
 
 /* ---- deterministic synthetic IQ source --------------------------------------- */
 typedef struct adsb_synth_cfg {

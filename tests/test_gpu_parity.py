@@ -1,11 +1,27 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle.  Bit-exact: frames, offsets,
 status and repaired-bit index must all be identical (integer/byte work, no tolerance)."""
+import os
+
 import numpy as np
 import pytest
 
 import air_rs_amd as A
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["stream", "tiles"], autouse=True)
+def kernel_kind(request):
+    """Every test of this module runs once per i8 tile kernel: the streaming kernel (default) and the
+    one-workgroup-per-tile kernel (ADSB_KERNEL=tiles, read at adsb_create).  i16 contexts always use the
+    tile kernel."""
+    old = os.environ.get("ADSB_KERNEL")
+    os.environ["ADSB_KERNEL"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("ADSB_KERNEL", None)
+    else:
+        os.environ["ADSB_KERNEL"] = old
 
 
 def _eq(got, want):
@@ -26,8 +42,9 @@ def _check(dem, oracle, iq, max_out=None):
 
 
 @pytest.fixture(scope="module")
-def dem8(gpu):
+def dem8(gpu, kernel_kind):
     with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 18) as d:
+        assert d.kernel == kernel_kind
         yield d
 
 
@@ -44,6 +61,17 @@ def test_magnitude_i8_exhaustive(dem8, oracle):
     got = dem8.magnitudes(iq)
     want = oracle.get_magnitude(iq.astype(np.int16))
     assert (got == want).all(), (dem8.mag_mode, np.nonzero(got != want)[0][:10])
+
+
+def test_magnitude_table_exhaustive(dem8, oracle, kernel_kind):
+    # the streaming kernel's 64 KB table: floor(sqrt(I^2+Q^2)) for every raw sample (Q << 8) | I
+    if kernel_kind != "stream":
+        pytest.skip("the tile kernel computes magnitudes arithmetically (test above)")
+    table = dem8.magnitude_table()
+    r = np.arange(65536, dtype=np.uint32)
+    iq = np.stack([(r & 0xFF).astype(np.uint8).view(np.int8), (r >> 8).astype(np.uint8).view(np.int8)], axis=1)
+    want = oracle.get_magnitude(iq.astype(np.int16))
+    assert (table == want).all(), np.nonzero(table != want)[0][:10]
 
 
 def test_magnitude_i16(dem16, oracle):
