@@ -60,6 +60,9 @@
 // VALU -> SGPR -> s_cbranch chain of every gate step being fully exposed) + four lookup waves.
 constexpr int kSGateThreads = 512;           // 8 gate waves: 2 runs of kSRun offsets per lane
 constexpr int kSRun = kTile / (2 * kSGateThreads); // 32
+#ifndef ADSB_STREAM_D_AT
+#define ADSB_STREAM_D_AT 14 // gate step (of kSRun = 32) before which the gate waves take barrier D
+#endif
 #ifndef ADSB_STREAM_LOOKUP_WAVES
 #define ADSB_STREAM_LOOKUP_WAVES 8
 #endif
@@ -202,41 +205,159 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
     return v;
 }
 
-// ---- role: lookup waves (the last ADSB_STREAM_LOOKUP_WAVES) ---------------------------------------------------------------------
-// Per round i: convert the raw registers (tile i+1) into the other magnitude buffer, re-loading every
-// consumed register with tile i+2's data, then take part in the round's barriers.  The barrier count
-// per round depends on how many candidates the gate found; it is re-derived here from the same LDS
-// words the gate waves use, so both roles always execute the same number of s_barrier.
+// ---- PPM slice + CRC-24 + single-bit repair of one candidate by a 16-lane group --------------------------
+// Lane l slices frame byte l (magnitudes off+16+16l .. +15, demod.rs:97-101).  The 24-byte record
+// {offset, bytes[14], status, fixed_bit} is written to `rec` (LDS); returns (on every lane) whether the
+// frame is valid (CRC matched, or one data bit repaired: crc.rs:49-65).
+__device__ __forceinline__ bool decode_candidate(const unsigned char *mag, const uint32_t *syn, unsigned char *rec,
+                                                 const bool have, const uint32_t off, const uint64_t sample0,
+                                                 const uint32_t l, const uint32_t lane)
+{
+    const uint32_t lb = l < 14 ? l : 13;
+    uint32_t byte = 0;
+    {
+        const uint32_t pidx = off + 16 + 16 * lb;
+        const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
+        const uint32_t sh = pidx & 3;
+        uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
+        uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1: bit = (a > b)
+            // b - a per 16-bit half wraps (sets bit 15) exactly when a > b; no selects (v_cndmask
+            // issues four times slower than other VALU instructions here)
+            const u16x2 xa = __builtin_bit_cast(u16x2, w[k] & 0x00FF00FFu);
+            const u16x2 xb = __builtin_bit_cast(u16x2, (w[k] >> 8) & 0x00FF00FFu);
+            const uint32_t z = __builtin_bit_cast(uint32_t, (u16x2)(xb - xa)) & 0x80008000u;
+            byte |= ((z >> (8 + 2 * k)) & 0xFFu) | (z >> (25 + 2 * k));
+        }
+    }
+    // syndrome = XOR of table entries of the set bits, over the 14 bytes
+    uint32_t s = 0;
+    const uint32_t *sy = syn + 8 * lb;
+    {
+        const int sb = (int)(l < 14 ? byte : 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
+    }
+    s = row16_xor(s);
+    // single-bit repair: only the 88 data bits can match (crc.rs:49-65)
+    int found = -1;
+    if (s != 0 && l < 11) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
+    }
+    const unsigned long long fm = __ballot(found >= 0);
+    const uint32_t gsh = (lane & 48u);
+    const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
+    const bool valid = have && (s == 0 || gbits != 0);
+    uint32_t status = 0xFFu, fixed = 0xFFu;
+    if (valid) {
+        status = (s == 0) ? 0u : 1u;
+        if (s != 0) {
+            const uint32_t fl = __builtin_ctz(gbits);
+            const int fk = __shfl(found, (int)fl, 16);
+            fixed = 8 * fl + (uint32_t)fk;
+            if (l == fl) byte ^= 0x80u >> fk;
+        }
+    }
+    if (have) {
+        if (l < 14) rec[8 + l] = (unsigned char)byte;
+        if (l == 14) rec[22] = (unsigned char)status;
+        if (l == 15) rec[23] = (unsigned char)fixed;
+        if (l == 0) {
+            const uint64_t o64 = sample0 + off;
+            reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
+            reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
+        }
+    }
+    return valid;
+}
+
+// Barrier schedule shared by the two roles (every wave executes the same sequence of s_barrier):
+//   P1  table in LDS                      P2  tile 0 converted
+//   per round i = 0 .. n_my:   D(i)  inside the gate of tile i (the last round has no gate: bare D)
+//                              B1(i) after gate(i) and conversion(i+1)           [i < n_my]
+//                              dense rounds only (more than kSparseCap survivors): BD, BA, {BC1, BC2}*, X
+// Round i in the normal (sparse) case:
+//   gate waves    gate(i) first part | D(i) | gate(i) rest, then thread/wave 0 writes tile i-1's record and
+//                 its staged frames to global memory | B1(i)
+//   lookup waves  decode(i-1): survivors of tile i-1 -> frame records staged in LDS | D(i) | conversion of
+//                 tile i+1 into the buffer tile i-1 occupied, re-loading the raw registers with tile i+2 | B1(i)
+// The survivor list, the counters and the frame staging are double-buffered by round parity.
+
+// ---- role: lookup waves (the last ADSB_STREAM_LOOKUP_WAVES) ----------------------------------------------
 __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned char *smem, const uint32_t tg,
                                                    const uint32_t tile0, const uint32_t G, const uint32_t n_my)
 {
     typedef SLds L;
     const unsigned char *lut = smem + L::kOffLut;
-    const uint32_t *misc = reinterpret_cast<const uint32_t *>(smem + L::kOffMisc);
-    const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tg & ~63u) * 8; // first sample of this wave's sweep
+    const uint16_t *lists = reinterpret_cast<const uint16_t *>(smem + L::kOffList);
+    const uint32_t *syn = reinterpret_cast<const uint32_t *>(smem + L::kOffSyn);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
+    const uint32_t lane = tg & 63;
+    const uint32_t lwave = __builtin_amdgcn_readfirstlane(tg >> 6);
+    const uint32_t wave_s0 = lwave * 64 * 8; // first sample of this wave's sweep
+    const uint32_t g = tg >> 4, l = tg & 15;  // 16-lane decode groups
 
-    // Pass r converts tile r-1 (if 1 <= r <= n_my) from the raw registers into magnitude buffer (r-1)&1
-    // and re-loads every consumed register, in place, with the same piece of tile r (if r < n_my;
-    // otherwise through an empty descriptor: zeros, no traffic).  Pass 0 and the last pass convert zeros
-    // into a buffer nobody reads: one uniform, branch-free body.  All loads are issued unconditionally:
-    // lanes past the tile's samples -- most of the last sweep, which only covers the 256-sample halo --
-    // are clipped by the descriptor and cost no traffic.
+    // Conversion pass r converts tile r-1 (if 1 <= r <= n_my) from the raw registers into magnitude buffer
+    // (r-1)&1 and re-loads every consumed register, in place, with the same piece of tile r (if r < n_my;
+    // otherwise through an empty descriptor: zeros, no traffic).  Pass 0 and the passes after n_my convert
+    // zeros into a buffer nobody reads: one uniform, branch-free body.  All loads are issued
+    // unconditionally: lanes past the tile's samples -- most of the last sweep, which only covers the
+    // 256-sample halo -- are clipped by the descriptor and cost no traffic.
     //
     // The loads and their waits are inline asm.  With the builtin, every formulation tried made hipcc
-    // either drain (s_waitcnt vmcnt(0)) or rotate the 17 register quads through 68 v_mov per pass,
+    // either drain (s_waitcnt vmcnt(0)) or rotate the register quads through one v_mov each per pass,
     // because it cannot keep a load that is in flight across the loop's back edge in the register it
     // will be consumed from.  Tied operands ("+v") pin each quad; the wait is explicit: when sweep `it`
-    // is consumed, the kSIters - 1 loads issued after its own (the rest of the previous pass, the start of this
-    // one) may still be in flight -> s_waitcnt vmcnt(kSIters - 1).  These waves issue no other vector memory
-    // instruction, so the count is exact.  (hipcc must not copy a quad between its load and its wait:
-    // checked in the ISA -- no v_mov touches them.)
+    // is consumed, the kSIters - 1 loads issued after its own (the rest of the previous pass, the start of
+    // this one) may still be in flight -> s_waitcnt vmcnt(kSIters - 1).  These waves issue no other vector
+    // memory instruction (decoded frames are staged in LDS and stored by a gate wave), so the count is
+    // exact.  (hipcc must not copy a quad between its load and its wait: checked in the ISA.)
     u32x4 raw[kSIters];
 #pragma unroll
     for (int it = 0; it < kSIters; ++it) raw[it] = u32x4{0u, 0u, 0u, 0u};
 
     STAMP_DECL;
     STAMP_START();
-    for (uint32_t r = 0; r <= n_my + 1; ++r) {
+    bool prev_dense = false; // round r-3 took the dense path (its frames are already in global memory)
+    for (uint32_t r = 0; r <= n_my + 2; ++r) {
+        // ---- decode of tile r-3 (round i-1 for i = r-2), then D(i) ----------------------------------------
+        if (r >= 2) {
+            if (r >= 3 && !prev_dense) {
+                const uint32_t jp = (r - 3) & 1u;
+                const uint32_t total = misc[L::kCount + jp];
+                if (total) {
+                    const uint16_t *list = lists + jp * kListCap;
+                    const unsigned char *mag = smem + (jp ? L::kOffMag1 : L::kOffMag0);
+                    unsigned char *stage = smem + L::kOffStage + jp * (kSparseCap * 24);
+                    const TilePos tpd = tile_pos(p, tile0 + (r - 3) * G);
+                    // The list is unordered; a candidate's slot is its rank: the number of listed offsets
+                    // below its own.  total <= kSparseCap = 64 = 16 lanes x 4.
+                    for (uint32_t c0 = 0; c0 < total; c0 += kSLookupThreads / 16) {
+                        if (c0 + 4 * lwave >= total) break; // none of this wave's four groups has a candidate
+                        const uint32_t ci = c0 + g;
+                        const bool have = ci < total; // uniform within the 16-lane group
+                        const uint32_t off = have ? list[ci] : 0u;
+                        uint32_t below = 0;
+#pragma unroll
+                        for (int k = 0; k < kSparseCap / 16; ++k) {
+                            const uint32_t j = l + 16 * k;
+                            const uint32_t e = j < total ? (uint32_t)list[j] : 0xFFFFFFFFu;
+                            below += e < off ? 1u : 0u;
+                        }
+                        below = row16_sum(below);
+                        const bool valid = decode_candidate(mag, syn, stage + (have ? below : 0u) * 24, have, off, tpd.sample0, l, lane);
+                        if (valid && l == 0) atomicAdd(&misc[L::kValid + jp], 1u);
+                    }
+                }
+            }
+            STAMP(3); // decode
+            __syncthreads(); // D(i)
+            STAMP(1);
+        }
+        // ---- conversion pass r ---------------------------------------------------------------------------
         unsigned char *dst = smem + ((r & 1u) ? L::kOffMag0 : L::kOffMag1); // buffer (r-1)&1
         const bool more = r < n_my;
         const TilePos tpn = tile_pos(p, more ? tile0 + r * G : tile0);
@@ -255,8 +376,8 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
                 *reinterpret_cast<uint2 *>(dst + (uint32_t)(it - 1) * (kSLookupThreads * 8) + tg * 8) = lookup_pack(mprev);
 #pragma unroll
             for (int k = 0; k < 8; ++k) mprev[k] = m[k];
-            // keep the sweeps in program order (hipcc would otherwise hoist all 16 index computations,
-            // and with them the waits, to the top of the pass)
+            // keep the sweeps in program order (hipcc would otherwise hoist all index computations, and
+            // with them the waits, to the top of the pass)
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!ADSB_ABL_NOLOOKUP)
@@ -276,26 +397,24 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
             }
         }
         STAMP(0); // conversion pass
-        __syncthreads(); // P1 (r = 0: table in LDS), P2 (r = 1: tile 0 converted), B1 of round r - 2
-        STAMP(1); // wait for the gate waves
+        if (r == n_my + 2) break; // round n_my has no B1
+        __syncthreads(); // P1 (r = 0), P2 (r = 1), B1(r - 2)
+        STAMP(2); // wait for the gate waves
         if (r < 2) continue;
-        // mirror of the gate role's barriers for round r - 2
+        // mirror of the gate role's barriers for round i = r - 2
         const uint32_t par = r & 1u;
         uint32_t total = misc[L::kCount + par];
-        const bool dense = total > (uint32_t)kSparseCap;
-        if (dense) {
+        prev_dense = total > (uint32_t)kSparseCap;
+        if (prev_dense) {
             __syncthreads(); // BD
             total = misc[0] + misc[1] + misc[2] + misc[3];
-        }
-        if (total > kQuota) __syncthreads(); // BA
-        if (dense) {
+            __syncthreads(); // BA
             for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
                 __syncthreads(); // BC1
                 __syncthreads(); // BC2
             }
+            __syncthreads(); // X
         }
-        __syncthreads(); // X
-        STAMP(2); // the gate waves' decode
     }
     // nothing may be in flight into registers when the wave ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -305,11 +424,7 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
 #endif
 }
 
-// ---- role: gate waves (the first eight) -----------------------------------------------------------------------
-// Per round i: preamble/DF17 gate of tile i from its magnitude buffer, then PPM slice, CRC-24 and
-// single-bit repair of the survivors.  Two barriers per round in the normal (sparse) case: B1 after the
-// gate, X after the decode; the survivor list and the counters are double-buffered by round parity so
-// that thread 0 can write the tile's record while the other waves already gate the next tile.
+// ---- role: gate waves (the first eight) --------------------------------------------------------------------
 __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned char *smem, const uint32_t tid,
                                                  const uint32_t tile0, const uint32_t G, const uint32_t n_my)
 {
@@ -322,128 +437,87 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
     const uint32_t lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t g = tid >> 4, l = tid & 15; // kSGroups groups of 16 lanes: one candidate each, one lane per frame byte
+    const uint32_t g = tid >> 4, l = tid & 15; // kSGroups groups of 16 lanes (dense path decode)
 
     __syncthreads(); // P1
     __syncthreads(); // P2: tile 0's magnitudes are in buffer 0
     STAMP_DECL;
     STAMP_START();
 
-    // Per-tile record (Seg + group counters) of a finished round; its counters are re-armed for the round
-    // after next (same parity; barriers B1 and X of the round in between order that).
-    bool rec_pending = false;
+    // Record of a finished sparse round, written by wave 0 one round later (after the next gate, where
+    // the gate waves wait for the lookup waves anyway): the frames the lookup waves staged in LDS go to
+    // the tile's slots, then Seg + group counters; the round's counters are re-armed for the round after
+    // next (same parity; D and B1 of the round in between order that).
+    bool rec_pending = false, rec_dense = false;
     uint32_t rec_tile = 0, rec_base = 0, rec_total = 0, rec_par = 0;
     auto record = [&]() {
-        if (tid == 0 && rec_pending) {
-            const uint32_t rp = rec_par;
-            Seg e;
-            e.base = rec_base;
-            e.cand = rec_total;
-            e.valid = misc[L::kValid + rp];
-            e.pad = 0;
-            p.seg[rec_tile] = e;
-            if (e.valid && p.count_groups) {
-                atomicAdd(&p.grp1[rec_tile >> kGrpShift], e.valid);
-                atomicAdd(&p.grp2[(rec_tile >> (2 * kGrpShift)) * kGrp2Shards + ((rec_tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
+        if (wave == 0 && rec_pending) {
+            if (!rec_dense && rec_base != kNoBase) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(smem + L::kOffStage + rec_par * (kSparseCap * 24));
+                uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)rec_base);
+                for (uint32_t k = lane; k < rec_total * 6; k += 64) dst[k] = src[k];
             }
-            misc[L::kValid + rp] = 0;
-            misc[L::kCount + rp] = 0;
+            if (lane == 0) {
+                Seg e;
+                e.base = rec_base;
+                e.cand = rec_total;
+                e.valid = misc[L::kValid + rec_par];
+                e.pad = 0;
+                p.seg[rec_tile] = e;
+                if (e.valid && p.count_groups) {
+                    atomicAdd(&p.grp1[rec_tile >> kGrpShift], e.valid);
+                    atomicAdd(&p.grp2[(rec_tile >> (2 * kGrpShift)) * kGrp2Shards + ((rec_tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
+                }
+                misc[L::kValid + rec_par] = 0;
+                misc[L::kCount + rec_par] = 0;
+            }
         }
+        rec_pending = false;
     };
 
-    for (uint32_t i = 0; i < n_my; ++i) {
-        const uint32_t tile = tile0 + i * G;
+    for (uint32_t i = 0; i <= n_my; ++i) {
+        const bool live = i < n_my;
+        const uint32_t tile = tile0 + (live ? i : 0u) * G;
         const TilePos tp = tile_pos(p, tile);
         const uint64_t sample0 = tp.sample0;
         const unsigned char *mag = smem + ((i & 1u) ? L::kOffMag1 : L::kOffMag0);
         const uint32_t par = i & 1u;
         uint16_t *list = lists + par * kListCap;
 
-        if (!ADSB_ABL_NOGATE)
-            gate_phase<ST, ADSB_STREAM_GATE_GROUP, kSRun, kSGateThreads>(mag, cand, list, &misc[L::kCount + par], tid, tp.n_valid);
+        if (live && !ADSB_ABL_NOGATE) {
+            gate_phase<ST, ADSB_STREAM_GATE_GROUP, kSRun, kSGateThreads, ADSB_STREAM_D_AT>(
+                mag, cand, list, &misc[L::kCount + par], tid, tp.n_valid, [] { __syncthreads(); /* D(i) */ });
+        } else {
+            __syncthreads(); // D(i)
+        }
         STAMP(0); // gate
-        record(); // of the previous round
+        record(); // of round i - 1
         STAMP(6);
-        __syncthreads(); // B1: survivors listed; the lookup waves have filled the other buffer
+        if (!live) break;
+        __syncthreads(); // B1(i): survivors listed; the lookup waves have filled the other buffer
         STAMP(1); // wait for the lookup waves
-
-        // PPM slice + CRC-24 + single-bit repair of one candidate by a 16-lane group; the 24-byte record
-        // goes to frame slot `slot` of the tile (slots are in offset order: the gather pass relies on it).
-        auto decode = [&](const bool have, const uint32_t off, const uint32_t base_slot, const uint32_t slot) {
-            // lane l slices frame byte l: magnitudes off+16+16l .. off+16+16l+15  (demod.rs:97-101)
-            const uint32_t lb = l < 14 ? l : 13;
-            uint32_t byte = 0;
-            {
-                const uint32_t pidx = off + 16 + 16 * lb;
-                const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
-                const uint32_t sh = pidx & 3;
-                uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
-                uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                                 __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1: bit = (a > b)
-                    // b - a per 16-bit half wraps (sets bit 15) exactly when a > b; no selects (v_cndmask
-                    // issues four times slower than other VALU instructions here)
-                    const u16x2 xa = __builtin_bit_cast(u16x2, w[k] & 0x00FF00FFu);
-                    const u16x2 xb = __builtin_bit_cast(u16x2, (w[k] >> 8) & 0x00FF00FFu);
-                    const uint32_t z = __builtin_bit_cast(uint32_t, (u16x2)(xb - xa)) & 0x80008000u;
-                    byte |= ((z >> (8 + 2 * k)) & 0xFFu) | (z >> (25 + 2 * k));
-                }
-            }
-            // syndrome = XOR of table entries of the set bits, over the 14 bytes
-            uint32_t s = 0;
-            const uint32_t *sy = syn + 8 * lb;
-            {
-                const int sb = (int)(l < 14 ? byte : 0u);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
-            }
-            s = row16_xor(s);
-            // single-bit repair: only the 88 data bits can match (crc.rs:49-65)
-            int found = -1;
-            if (s != 0 && l < 11) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
-            }
-            const unsigned long long fm = __ballot(found >= 0);
-            const uint32_t gsh = (lane & 48u);
-            const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
-            const bool valid = have && (s == 0 || gbits != 0);
-            uint32_t status = 0xFFu, fixed = 0xFFu;
-            if (valid) {
-                status = (s == 0) ? 0u : 1u;
-                if (s != 0) {
-                    const uint32_t fl = __builtin_ctz(gbits);
-                    const int fk = __shfl(found, (int)fl, 16);
-                    fixed = 8 * fl + (uint32_t)fk;
-                    if (l == fl) byte ^= 0x80u >> fk;
-                }
-            }
-            // stage the 24-byte record, then 6 lanes store it as dwords
-            unsigned char *rec = res + g * 24;
-            if (l < 14) rec[8 + l] = (unsigned char)byte;
-            if (l == 14) rec[22] = (unsigned char)status;
-            if (l == 15) rec[23] = (unsigned char)fixed;
-            if (l == 0) {
-                const uint64_t o64 = sample0 + off;
-                reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
-                reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
-                if (valid) atomicAdd(&misc[L::kValid + par], 1u);
-            }
-            if (have && base_slot != kNoBase && l < 6) {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + slot);
-                dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
-            }
-        };
 
         uint32_t total = misc[L::kCount + par];
         const bool dense = total > (uint32_t)kSparseCap;
-        u32x4 cw = {0, 0, 0, 0};
-        uint32_t cnt = 0, my_first = 0;
-        if (dense) {
-            // dense fallback: ordered compaction of the bitmap (1024 words; offset 32 w + b is bit b of
-            // word w) by prefix sums over the first four gate waves, four words per lane
-            uint32_t incl = 0;
+        uint32_t base_slot = tile * kQuota;
+        if (!dense) {
+            // Normal case: nothing more to do here; the lookup waves decode the survivors next round.
+            // Over-quota tiles draw their slots from the shared pool (thread 0; the result is only needed
+            // by wave 0's record()).
+            if (total > kQuota && wave == 0) {
+                uint32_t b = 0;
+                if (lane == 0) {
+                    const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+                    b = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
+                }
+                base_slot = __builtin_amdgcn_readfirstlane(b);
+            }
+        } else {
+            // Dense fallback (pathological inputs): ordered compaction of the bitmap (1024
+            // words; offset 32 w + b is bit b of word w) by prefix sums over the first four gate waves, four
+            // words per lane; decode in place by the gate waves, straight to global memory.
+            u32x4 cw = {0, 0, 0, 0};
+            uint32_t cnt = 0, incl = 0;
             if (wave < 4) {
                 cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
                 cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) +
@@ -465,39 +539,13 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
                 wbase += (w < (int)wave) ? t : 0u;
                 total += t;
             }
-            my_first = wbase + incl - cnt;
-        }
-        // Frame slots: the tile's own fixed region when the survivors fit (no atomics), otherwise one
-        // allocation from the shared pool.
-        uint32_t base_slot = tile * kQuota;
-        if (total > kQuota) {
+            const uint32_t my_first = wbase + incl - cnt;
             if (tid == 0) {
                 const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
                 misc[L::kAlloc] = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
             }
             __syncthreads(); // BA
             base_slot = misc[L::kAlloc];
-        }
-        if (!dense) {
-            // The list is unordered; a candidate's slot is its rank: the number of listed offsets below
-            // its own (no separate sort step, no barrier).  total <= kSparseCap = 64 = 16 lanes x 4.
-            for (uint32_t r = 0; r < total; r += kSGroups) {
-                if (r + 4 * wave >= total) break; // none of this wave's four groups has a candidate
-                const uint32_t ci = r + g;
-                const bool have = ci < total; // uniform within the 16-lane group
-                const uint32_t off = have ? list[ci] : 0u;
-                uint32_t below = 0;
-#pragma unroll
-                for (int k = 0; k < kSparseCap / 16; ++k) {
-                    const uint32_t j = l + 16 * k;
-                    const uint32_t e = j < total ? (uint32_t)list[j] : 0xFFFFFFFFu;
-                    below += e < off ? 1u : 0u;
-                }
-                below = row16_sum(below);
-                decode(have, off, base_slot, below);
-            }
-            STAMP(4); // decode
-        } else {
             for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
                 if (cnt) {
                     uint32_t idx = my_first;
@@ -520,22 +568,25 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
                     if (r + 4 * wave >= ncl) break;
                     const uint32_t ci = r + g;
                     const bool have = ci < ncl;
-                    decode(have, have ? list[ci] : 0u, base_slot, chunk + ci);
+                    unsigned char *rec = res + g * 24;
+                    const bool valid = decode_candidate(mag, syn, rec, have, have ? list[ci] : 0u, sample0, l, lane);
+                    if (valid && l == 0) atomicAdd(&misc[L::kValid + par], 1u);
+                    if (have && base_slot != kNoBase && l < 6) {
+                        uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);
+                        dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
+                    }
                 }
                 __syncthreads(); // BC2
             }
+            __syncthreads(); // X: in-place decode done before the lookup waves overwrite the buffer
         }
-        __syncthreads(); // X: decode done; this round's magnitude buffer, bitmap and staging are free
-        STAMP(5);
-        // the tile's record is written by thread 0 after the NEXT gate (where the gate waves wait for the
-        // lookup waves anyway), not here on the critical path
         rec_pending = true;
+        rec_dense = dense;
         rec_tile = tile;
         rec_base = base_slot;
         rec_total = total;
         rec_par = par;
     }
-    record();
 #if ADSB_STAMPS
     if (blockIdx.x == 0 && tid == 0 && p.stamps) {
         for (int k = 0; k < 8; ++k) p.stamps[k] = st_acc[k];

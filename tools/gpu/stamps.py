@@ -17,11 +17,11 @@ for _ in range(3):
 dem.fetch_counts()
 s = dem.stamps()
 rounds = max(int(s[15]), 1)
-names = ["gate", "wait B1 (lookup waves)", "-", "-", "decode", "wait X", "record (prev. round)", "-",
-         "lookup: conversion pass", "lookup: wait for gate waves", "lookup: gate waves' decode", "-"]
+names = ["gate (incl. barrier D)", "wait B1 (lookup waves)", "-", "-", "-", "-", "record (prev. round)", "-",
+         "lookup: conversion pass", "lookup: wait at D", "lookup: wait at B1", "lookup: decode (prev. round)"]
 print(f"kernel {dem.kernel}, rounds {rounds}")
 for k, nm in enumerate(names):
     if nm != "-":
         print(f"  {nm:32s} {int(s[k]) / rounds:10.0f} cycles/round")
 print(f"  gate-wave round total            {sum(int(x) for x in s[:7]) / rounds:10.0f}")
-print(f"  lookup-wave round total          {sum(int(x) for x in s[8:11]) / rounds:10.0f}")
+print(f"  lookup-wave round total          {sum(int(x) for x in s[8:12]) / rounds:10.0f}")
