@@ -238,6 +238,101 @@ __device__ __forceinline__ uint32_t pair_at_cold(const uint32_t *ra, const uint3
     }
 }
 
+// XOR / sum over each row of 16 lanes (a decode group), result in every lane: four DPP steps (VALU
+// latency each) instead of four ds_bpermute round trips through the LDS.
+#define ADSB_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ uint32_t row16_xor(uint32_t v)
+{
+    v ^= ADSB_DPP(v, 0xB1);  // quad_perm [1,0,3,2]
+    v ^= ADSB_DPP(v, 0x4E);  // quad_perm [2,3,0,1]
+    v ^= ADSB_DPP(v, 0x141); // row_half_mirror
+    v ^= ADSB_DPP(v, 0x140); // row_mirror
+    return v;
+}
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v)
+{
+    v += ADSB_DPP(v, 0xB1);
+    v += ADSB_DPP(v, 0x4E);
+    v += ADSB_DPP(v, 0x141);
+    v += ADSB_DPP(v, 0x140);
+    return v;
+}
+
+// ---- PPM slice + CRC-24 + single-bit repair of one candidate by a 16-lane group --------------------------
+// Lane l slices frame byte l (magnitudes off+16+16l .. +15, demod.rs:97-101).  The 24-byte record
+// {offset, bytes[14], status, fixed_bit} is written to `rec` (LDS); returns (on every lane) whether the
+// frame is valid (CRC matched, or one data bit repaired: crc.rs:49-65).
+template <int ST>
+__device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *mag, const uint32_t *syn, unsigned char *rec,
+                                                 const bool have, const uint32_t off, const uint64_t sample0,
+                                                 const uint32_t l, const uint32_t lane)
+{
+    const uint32_t lb = l < 14 ? l : 13;
+    uint32_t byte = 0;
+    if (ST == ADSB_SAMPLE_I16) {
+        const typename MagT<ST>::type *mp = mag + off + 16 + 16 * lb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) // b - a is negative exactly when a > b (magnitudes < 2^16)
+            byte |= (((uint32_t)mp[2 * k + 1] - (uint32_t)mp[2 * k]) >> 31) << (7 - k);
+    } else {
+        const uint32_t pidx = off + 16 + 16 * lb;
+        const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
+        const uint32_t sh = pidx & 3;
+        uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
+        uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1: bit = (a > b)
+            // b - a per 16-bit half wraps (sets bit 15) exactly when a > b; no selects (v_cndmask
+            // issues four times slower than other VALU instructions here)
+            const u16x2 xa = __builtin_bit_cast(u16x2, w[k] & 0x00FF00FFu);
+            const u16x2 xb = __builtin_bit_cast(u16x2, (w[k] >> 8) & 0x00FF00FFu);
+            const uint32_t z = __builtin_bit_cast(uint32_t, (u16x2)(xb - xa)) & 0x80008000u;
+            byte |= ((z >> (8 + 2 * k)) & 0xFFu) | (z >> (25 + 2 * k));
+        }
+    }
+    // syndrome = XOR of table entries of the set bits, over the 14 bytes
+    uint32_t s = 0;
+    const uint32_t *sy = syn + 8 * lb;
+    {
+        const int sb = (int)(l < 14 ? byte : 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
+    }
+    s = row16_xor(s);
+    // single-bit repair: only the 88 data bits can match (crc.rs:49-65)
+    int found = -1;
+    if (s != 0 && l < 11) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
+    }
+    const unsigned long long fm = __ballot(found >= 0);
+    const uint32_t gsh = (lane & 48u);
+    const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
+    const bool valid = have && (s == 0 || gbits != 0);
+    uint32_t status = 0xFFu, fixed = 0xFFu;
+    if (valid) {
+        status = (s == 0) ? 0u : 1u;
+        if (s != 0) {
+            const uint32_t fl = __builtin_ctz(gbits);
+            const int fk = __shfl(found, (int)fl, 16);
+            fixed = 8 * fl + (uint32_t)fk;
+            if (l == fl) byte ^= 0x80u >> fk;
+        }
+    }
+    if (have) {
+        if (l < 14) rec[8 + l] = (unsigned char)byte;
+        if (l == 14) rec[22] = (unsigned char)status;
+        if (l == 15) rec[23] = (unsigned char)fixed;
+        if (l == 0) {
+            const uint64_t o64 = sample0 + off;
+            reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
+            reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
+        }
+    }
+    return valid;
+}
+
 // Where a tile sits: global tile id -> channel, first sample, number of valid offsets.
 struct TilePos {
     uint32_t ch;
@@ -525,15 +620,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         const bool dense = total > (uint32_t)kSparseCap;
         u32x4 cw = {0, 0, 0, 0};
         uint32_t cnt = 0, my_first = 0;
-        if (!dense) {
-            // rank sort by one wave: entry i goes to position #{j : list[j] < list[i]}
-            if (wave == 0) {
-                const uint32_t e = lane < total ? list[lane] : 0xFFFFu;
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < total; ++j) rank += (list[j] < e) ? 1u : 0u;
-                if (lane < total) list[rank] = (uint16_t)e;
-            }
-        } else {
+        if (dense) {
             // dense fallback: ordered compaction of the bitmap by workgroup-wide prefix sums
             cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
             cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) +
@@ -594,74 +681,24 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 const uint32_t ci = r + g;
                 const bool have = ci < ncl; // uniform within the 16-lane group
                 const uint32_t off = have ? list[ci] : 0u;
-                // lane l slices frame byte l: magnitudes off+16+16l .. off+16+16l+15  (demod.rs:97-101)
-                const uint32_t lb = l < 14 ? l : 13;
-                uint32_t byte = 0;
-                {
-                    const uint32_t pidx = off + 16 + 16 * lb; // magnitude index of the byte's first sample
-                    if (ST == ADSB_SAMPLE_I8) {
-                        const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
-                        const uint32_t sh = pidx & 3;
-                        uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
-                        uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+                // sparse path: the list is unordered; the slot is the candidate's rank among the listed
+                // offsets (total <= kSparseCap = 64 = 16 lanes x 4)
+                uint32_t slot = ci;
+                if (!dense) {
+                    uint32_t below = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { // dword k holds pairs 2k and 2k+1
-                            byte |= ((w[k] & 0xFFu) > ((w[k] >> 8) & 0xFFu)) ? (0x80u >> (2 * k)) : 0u;
-                            byte |= (((w[k] >> 16) & 0xFFu) > (w[k] >> 24)) ? (0x40u >> (2 * k)) : 0u;
-                        }
-                    } else {
-                        const mag_t *mp = mag + pidx;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            byte |= (mp[2 * k] > mp[2 * k + 1]) ? (0x80u >> k) : 0u;
+                    for (int k = 0; k < kSparseCap / 16; ++k) {
+                        const uint32_t j = l + 16 * k;
+                        const uint32_t e = j < total ? (uint32_t)list[j] : 0xFFFFFFFFu;
+                        below += e < off ? 1u : 0u;
                     }
+                    slot = row16_sum(below);
                 }
-                // syndrome = XOR of table entries of the set bits, over the 14 bytes
-                uint32_t s = 0;
-                const uint32_t *sy = syn + 8 * lb;
-                if (l < 14) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) s ^= (byte & (0x80u >> k)) ? sy[k] : 0u;
-                }
-                s ^= __shfl_xor(s, 1, 16);
-                s ^= __shfl_xor(s, 2, 16);
-                s ^= __shfl_xor(s, 4, 16);
-                s ^= __shfl_xor(s, 8, 16);
-                // single-bit repair: only the 88 data bits can match (crc.rs:49-65; flips in the CRC
-                // field leave the computed CRC unchanged, so they never match the received one)
-                int found = -1;
-                if (s != 0 && l < 11) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
-                }
-                const unsigned long long fm = __ballot(found >= 0);
-                const uint32_t gsh = (lane & 48u);
-                const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
-                const bool valid = have && (s == 0 || gbits != 0);
-                uint32_t status = 0xFFu, fixed = 0xFFu;
-                if (valid) {
-                    status = (s == 0) ? 0u : 1u;
-                    if (s != 0) {
-                        const uint32_t fl = __builtin_ctz(gbits);
-                        const int fk = __shfl(found, (int)fl, 16);
-                        fixed = 8 * fl + (uint32_t)fk;
-                        if (l == fl) byte ^= 0x80u >> fk;
-                    }
-                }
-                // stage the 24-byte record, then 6 lanes store it as dwords
                 unsigned char *rec = res + g * 24;
-                if (l < 14) rec[8 + l] = (unsigned char)byte;
-                if (l == 14) rec[22] = (unsigned char)status;
-                if (l == 15) rec[23] = (unsigned char)fixed;
-                if (l == 0) {
-                    const uint64_t o64 = sample0 + off;
-                    reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
-                    reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
-                    if (valid) atomicAdd(&misc[8], 1u);
-                }
+                const bool valid = decode_candidate<ST>(mag, syn, rec, have, off, sample0, l, lane);
+                if (valid && l == 0) atomicAdd(&misc[8], 1u);
                 if (have && base_slot != kNoBase && l < 6) {
-                    uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + slot);
                     dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
                 }
             }

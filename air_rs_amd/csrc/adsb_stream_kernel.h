@@ -185,95 +185,6 @@ __device__ __forceinline__ uint2 lookup_pack(const uint32_t m[8])
     return make_uint2(__builtin_amdgcn_perm(p1, p0, 0x06040200u), __builtin_amdgcn_perm(p3, p2, 0x06040200u));
 }
 
-// XOR / sum over each row of 16 lanes (a decode group), result in every lane: four DPP steps (VALU
-// latency each) instead of four ds_bpermute round trips through the LDS.
-#define ADSB_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
-__device__ __forceinline__ uint32_t row16_xor(uint32_t v)
-{
-    v ^= ADSB_DPP(v, 0xB1);  // quad_perm [1,0,3,2]
-    v ^= ADSB_DPP(v, 0x4E);  // quad_perm [2,3,0,1]
-    v ^= ADSB_DPP(v, 0x141); // row_half_mirror
-    v ^= ADSB_DPP(v, 0x140); // row_mirror
-    return v;
-}
-__device__ __forceinline__ uint32_t row16_sum(uint32_t v)
-{
-    v += ADSB_DPP(v, 0xB1);
-    v += ADSB_DPP(v, 0x4E);
-    v += ADSB_DPP(v, 0x141);
-    v += ADSB_DPP(v, 0x140);
-    return v;
-}
-
-// ---- PPM slice + CRC-24 + single-bit repair of one candidate by a 16-lane group --------------------------
-// Lane l slices frame byte l (magnitudes off+16+16l .. +15, demod.rs:97-101).  The 24-byte record
-// {offset, bytes[14], status, fixed_bit} is written to `rec` (LDS); returns (on every lane) whether the
-// frame is valid (CRC matched, or one data bit repaired: crc.rs:49-65).
-__device__ __forceinline__ bool decode_candidate(const unsigned char *mag, const uint32_t *syn, unsigned char *rec,
-                                                 const bool have, const uint32_t off, const uint64_t sample0,
-                                                 const uint32_t l, const uint32_t lane)
-{
-    const uint32_t lb = l < 14 ? l : 13;
-    uint32_t byte = 0;
-    {
-        const uint32_t pidx = off + 16 + 16 * lb;
-        const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
-        const uint32_t sh = pidx & 3;
-        uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
-        uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1: bit = (a > b)
-            // b - a per 16-bit half wraps (sets bit 15) exactly when a > b; no selects (v_cndmask
-            // issues four times slower than other VALU instructions here)
-            const u16x2 xa = __builtin_bit_cast(u16x2, w[k] & 0x00FF00FFu);
-            const u16x2 xb = __builtin_bit_cast(u16x2, (w[k] >> 8) & 0x00FF00FFu);
-            const uint32_t z = __builtin_bit_cast(uint32_t, (u16x2)(xb - xa)) & 0x80008000u;
-            byte |= ((z >> (8 + 2 * k)) & 0xFFu) | (z >> (25 + 2 * k));
-        }
-    }
-    // syndrome = XOR of table entries of the set bits, over the 14 bytes
-    uint32_t s = 0;
-    const uint32_t *sy = syn + 8 * lb;
-    {
-        const int sb = (int)(l < 14 ? byte : 0u);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
-    }
-    s = row16_xor(s);
-    // single-bit repair: only the 88 data bits can match (crc.rs:49-65)
-    int found = -1;
-    if (s != 0 && l < 11) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
-    }
-    const unsigned long long fm = __ballot(found >= 0);
-    const uint32_t gsh = (lane & 48u);
-    const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
-    const bool valid = have && (s == 0 || gbits != 0);
-    uint32_t status = 0xFFu, fixed = 0xFFu;
-    if (valid) {
-        status = (s == 0) ? 0u : 1u;
-        if (s != 0) {
-            const uint32_t fl = __builtin_ctz(gbits);
-            const int fk = __shfl(found, (int)fl, 16);
-            fixed = 8 * fl + (uint32_t)fk;
-            if (l == fl) byte ^= 0x80u >> fk;
-        }
-    }
-    if (have) {
-        if (l < 14) rec[8 + l] = (unsigned char)byte;
-        if (l == 14) rec[22] = (unsigned char)status;
-        if (l == 15) rec[23] = (unsigned char)fixed;
-        if (l == 0) {
-            const uint64_t o64 = sample0 + off;
-            reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
-            reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
-        }
-    }
-    return valid;
-}
-
 // Barrier schedule shared by the two roles (every wave executes the same sequence of s_barrier):
 //   P1  table in LDS                      P2  tile 0 converted
 //   per round i = 0 .. n_my:   D(i)  inside the gate of tile i (the last round has no gate: bare D)
@@ -348,7 +259,7 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
                             below += e < off ? 1u : 0u;
                         }
                         below = row16_sum(below);
-                        const bool valid = decode_candidate(mag, syn, stage + (have ? below : 0u) * 24, have, off, tpd.sample0, l, lane);
+                        const bool valid = decode_candidate<ADSB_SAMPLE_I8>(mag, syn, stage + (have ? below : 0u) * 24, have, off, tpd.sample0, l, lane);
                         if (valid && l == 0) atomicAdd(&misc[L::kValid + jp], 1u);
                     }
                 }
@@ -569,7 +480,7 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
                     const uint32_t ci = r + g;
                     const bool have = ci < ncl;
                     unsigned char *rec = res + g * 24;
-                    const bool valid = decode_candidate(mag, syn, rec, have, have ? list[ci] : 0u, sample0, l, lane);
+                    const bool valid = decode_candidate<ADSB_SAMPLE_I8>(mag, syn, rec, have, have ? list[ci] : 0u, sample0, l, lane);
                     if (valid && l == 0) atomicAdd(&misc[L::kValid + par], 1u);
                     if (have && base_slot != kNoBase && l < 6) {
                         uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);

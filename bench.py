@@ -57,10 +57,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-type", choices=["i8", "i16"], default="i8",
                     help="i8 = BASELINE metric (2 B/sample); i16 = the reference's Complex<i16> (4 B/sample)")
+    ap.add_argument("--kernel", choices=["default", "tiles", "stream"], default="default",
+                    help="i8 tile kernel: one workgroup per tile, or the streaming kernel (DESIGN.md section 4); "
+                         "default = the library's default (ADSB_KERNEL in the environment is honoured)")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the multi-rank frame-list gather even with one rank (testing)")
     args = ap.parse_args()
 
+    if args.kernel != "default":
+        os.environ["ADSB_KERNEL"] = args.kernel  # read by adsb_create
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,7 +210,8 @@ def main():
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": f"adsbk::demod_tiles<{args.sample_type}>", "kernel_ms": round(demod_ms, 4),
+                         "kernel": ("adsbk::demod_stream_i8" if dem.kernel == "stream"
+                                    else f"adsbk::demod_tiles<{args.sample_type}>"), "kernel_ms": round(demod_ms, 4),
                          "order_pass_ms": round(order_ms, 4), "launches_timed": n_timed,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "read_ceiling_gbps": round(float(bps) * n / (ceil_ms * 1e-3) / 1e9, 1)},

@@ -8,12 +8,13 @@ timeout -k 10 400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_o
 cat gpurun_out/parity.log
 [ $rc -ne 0 ] && exit $rc
 if [ -f air_rs_amd/lib/variants/libadsb_hip_stamps.so ]; then
-  ADSB_HIP_LIB=$PWD/air_rs_amd/lib/variants/libadsb_hip_stamps.so timeout -k 10 200 python tools/gpu/stamps.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/stamps.txt
+  ADSB_KERNEL=stream ADSB_HIP_LIB=$PWD/air_rs_amd/lib/variants/libadsb_hip_stamps.so timeout -k 10 200 python tools/gpu/stamps.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/stamps.txt
 fi
 : > gpurun_out/kernels.txt
 for v in default "$@" default; do
   lib=$PWD/air_rs_amd/lib/variants/libadsb_hip_$v.so
   [ "$v" = "default" ] && lib=$PWD/air_rs_amd/lib/libadsb_hip.so
+  [ "$v" = "tdefault" ] && lib=$PWD/air_rs_amd/lib/libadsb_hip.so
   k=stream; case $v in t*) k=tiles;; esac
   ADSB_KERNEL=$k ADSB_HIP_LIB=$lib timeout -k 10 200 python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>gpurun_out/bench_$v.err | python3 -c "
 import json,sys
