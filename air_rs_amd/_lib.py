@@ -50,6 +50,25 @@ class AdsbPacketFields(C.Structure):
                 ("callsign", C.c_char * 8)]
 
 
+class AdsbTrackPoint(C.Structure):
+    _fields_ = [("latitude", C.c_double), ("longitude", C.c_double), ("icao", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class AdsbAircraftRecord(C.Structure):
+    _fields_ = [("latitude", C.c_double), ("longitude", C.c_double), ("last_contact", C.c_double),
+                ("icao", C.c_uint32), ("altitude", C.c_int32), ("has_position", C.c_uint32),
+                ("n_frames", C.c_uint32), ("callsign", C.c_char * 8)]
+
+
+class AdsbAircraftSummary(C.Structure):
+    _fields_ = [("icao", C.c_uint32), ("callsign", C.c_char * 9), ("altitude", C.c_int32),
+                ("has_position", C.c_int32), ("latitude", C.c_double), ("longitude", C.c_double),
+                ("last_contact", C.c_double)]
+
+
+ADSB_TRACK_NEW_POSITION = 0x1
+
+
 class AdsbPacketView(C.Structure):
     _fields_ = [("packet", C.c_uint8 * 14), ("downlink_format", C.c_uint8), ("capability", C.c_uint8),
                 ("icao", C.c_uint32), ("msg_type", C.c_uint8), ("msg_kind", C.c_int32),
@@ -75,6 +94,17 @@ PROTOTYPES = {
     "adsb_decode_fields_device_async": (C.c_int, [C.c_void_p]),
     "adsb_fetch_fields": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "adsb_fields_device": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
+    "adsb_track_device": (C.c_int, [C.c_void_p, C.c_double]),
+    "adsb_fetch_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _P(C.c_size_t), C.c_void_p, C.c_size_t,
+                                   _P(C.c_size_t)]),
+    "adsb_cpr_num_zones": (C.c_uint32, [C.c_double]),
+    "adsb_cpr_position": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _P(C.c_double),
+                                    _P(C.c_double)]),
+    "adsb_tracker_create": (C.c_void_p, []),
+    "adsb_tracker_destroy": (None, [C.c_void_p]),
+    "adsb_tracker_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, _P(AdsbAircraftSummary)]),
+    "adsb_tracker_count": (C.c_size_t, [C.c_void_p]),
+    "adsb_tracker_get": (C.c_int, [C.c_void_p, C.c_uint32, _P(AdsbAircraftSummary)]),
     "adsb_stream": (C.c_void_p, [C.c_void_p]),
     "adsb_stream_wait_results": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adsb_set_result_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -49,6 +49,16 @@ struct adsb_ctx {
     hipStream_t aux = nullptr;      // ordering pass + result copies (== stream unless ADSB_OVERLAP_ORDERING=1)
     bool own_aux = false;
     adsb_packet_fields *fields = nullptr; // [max_out], allocated on first adsb_decode_fields_device_async
+    bool fields_current = false;    // fields[] belongs to the last launch
+    // tracker (allocated on first adsb_track_device)
+    uint32_t *trk_u32 = nullptr;    // 4 x [max_out]: keys, vals, sorted keys, sorted vals
+    void *trk_temp = nullptr;
+    size_t trk_temp_bytes = 0;
+    adsb_track_point *trk_points = nullptr;      // [max_out]
+    adsb_aircraft_record *trk_aircraft = nullptr; // [max_out]
+    uint64_t *trk_n_aircraft = nullptr;
+    uint32_t trk_n = 0;             // frames the last tracker run covered
+    bool trk_done = false;
     void *ext_blob = nullptr;       // caller-owned [32-byte header | frames] target for the next launches
     size_t ext_frames = 0;          // frame capacity of ext_blob
     adsb_frame *last_out = nullptr; // where the last launch's ordered list went
@@ -131,6 +141,11 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     }
     (void)hipFree(c->out_start);
     (void)hipFree(c->fields);
+    (void)hipFree(c->trk_u32);
+    (void)hipFree(c->trk_temp);
+    (void)hipFree(c->trk_points);
+    (void)hipFree(c->trk_aircraft);
+    (void)hipFree(c->trk_n_aircraft);
     (void)hipFree(c->scratch);
     (void)hipFree(c->lut);
     (void)hipFree(c->stamps);
@@ -348,6 +363,8 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_tpc = tiles_for(n_samples);
     c->last_tiles = c->last_tpc * n_channels;
     c->launched = true;
+    c->fields_current = false;
+    c->trk_done = false;
 
     // Launch i uses result set i&1 and counter set i%3; its ordering pass clears counter set
     // (i+2)%3 for launch i+2.  The demod kernel only has to wait for the ordering pass of launch
@@ -438,6 +455,8 @@ static int sync_header(adsb_ctx *c)
         int rc = rerun_in_batches(c, r);
         if (rc != ADSB_OK) return rc;
         c->hdr_host->retry = 0;
+        c->fields_current = false; // the list was rebuilt: decoded fields / tracker output are stale
+        c->trk_done = false;
     }
     return ADSB_OK;
 }
@@ -501,6 +520,7 @@ extern "C" int adsb_decode_fields_device_async(adsb_ctx *c)
         return ADSB_E_NOMEM;
     // same stream as the ordering pass, so it sees the finished list and header
     HIPCHK(adsbk::launch_decode_fields(c->aux, c->last_out, c->rs[c->last].hdr, c->last_cap, c->fields));
+    c->fields_current = true;
     return ADSB_OK;
 }
 
@@ -522,6 +542,67 @@ extern "C" int adsb_fetch_fields(adsb_ctx *c, adsb_packet_fields *out, size_t ma
     if (n) HIPCHK(hipMemcpyAsync(out, c->fields, sizeof(adsb_packet_fields) * n, hipMemcpyDeviceToHost, c->aux));
     HIPCHK(hipStreamSynchronize(c->aux));
     *n_out = (size_t)n;
+    return ADSB_OK;
+}
+
+
+extern "C" int adsb_track_device(adsb_ctx *c, double seconds_per_sample)
+{
+    if (!c || !(seconds_per_sample > 0.0)) return ADSB_E_ARG;
+    if (!c->launched) return ADSB_E_STATE;
+    if (c->last_channels != 1) return ADSB_E_ARG;
+    int rc = sync_header(c); // the list's length (and the rebuild after a slot-pool overflow)
+    if (rc != ADSB_OK) return rc;
+    if (!c->fields_current && (rc = adsb_decode_fields_device_async(c)) != ADSB_OK) return rc;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t cap = (size_t)c->cfg.max_out;
+    if (!c->trk_u32) {
+        c->trk_temp_bytes = adsbk::track_sort_temp_bytes(cap);
+        if (hipMalloc((void **)&c->trk_u32, sizeof(uint32_t) * 4 * cap) != hipSuccess ||
+            hipMalloc(&c->trk_temp, c->trk_temp_bytes) != hipSuccess ||
+            hipMalloc((void **)&c->trk_points, sizeof(adsb_track_point) * cap) != hipSuccess ||
+            hipMalloc((void **)&c->trk_aircraft, sizeof(adsb_aircraft_record) * cap) != hipSuccess ||
+            hipMalloc((void **)&c->trk_n_aircraft, sizeof(uint64_t)) != hipSuccess)
+            return ADSB_E_NOMEM;
+    }
+    const uint64_t n = std::min<uint64_t>(c->hdr_host->n_out, c->last_cap);
+    adsbk::TrackArgs a{};
+    a.frames = c->last_out;
+    a.fields = c->fields;
+    a.n = (uint32_t)n;
+    a.seconds_per_sample = seconds_per_sample;
+    a.keys = c->trk_u32;
+    a.vals = c->trk_u32 + cap;
+    a.skeys = c->trk_u32 + 2 * cap;
+    a.svals = c->trk_u32 + 3 * cap;
+    a.temp = c->trk_temp;
+    a.temp_bytes = c->trk_temp_bytes;
+    a.points = c->trk_points;
+    a.aircraft = c->trk_aircraft;
+    a.max_aircraft = (uint32_t)cap;
+    a.n_aircraft = c->trk_n_aircraft;
+    HIPCHK(adsbk::launch_track(c->aux, a)); // same stream as the ordering pass and the field decode
+    c->trk_n = (uint32_t)n;
+    c->trk_done = true;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_fetch_track(adsb_ctx *c, adsb_track_point *points, size_t max_points, size_t *n_points,
+                                adsb_aircraft_record *aircraft, size_t max_aircraft, size_t *n_aircraft)
+{
+    if (!c || (!points && max_points) || (!aircraft && max_aircraft)) return ADSB_E_ARG;
+    if (!c->trk_done) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    uint64_t na = 0;
+    HIPCHK(hipMemcpyAsync(&na, c->trk_n_aircraft, sizeof(uint64_t), hipMemcpyDeviceToHost, c->aux));
+    HIPCHK(hipStreamSynchronize(c->aux));
+    const size_t np = std::min<size_t>(c->trk_n, max_points);
+    const size_t nac = std::min<size_t>((size_t)na, max_aircraft);
+    if (np) HIPCHK(hipMemcpyAsync(points, c->trk_points, sizeof(adsb_track_point) * np, hipMemcpyDeviceToHost, c->aux));
+    if (nac) HIPCHK(hipMemcpyAsync(aircraft, c->trk_aircraft, sizeof(adsb_aircraft_record) * nac, hipMemcpyDeviceToHost, c->aux));
+    HIPCHK(hipStreamSynchronize(c->aux));
+    if (n_points) *n_points = np;
+    if (n_aircraft) *n_aircraft = (size_t)na;
     return ADSB_OK;
 }
 

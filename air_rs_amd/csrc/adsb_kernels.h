@@ -109,6 +109,23 @@ hipError_t launch_build_lut(hipStream_t s, uint8_t *lut_dev);
 hipError_t launch_decode_fields(hipStream_t s, const adsb_frame *frames, const Header *hdr, uint32_t cap,
                                 adsb_packet_fields *out);
 
+// tracker + CPR position decode over an ordered frame list (adsb_track.hip)
+struct TrackArgs {
+    const adsb_frame *frames;
+    const adsb_packet_fields *fields;
+    uint32_t n;                  // frames in the list (host value)
+    double seconds_per_sample;
+    uint32_t *keys, *vals, *skeys, *svals; // [n] each (keys/vals are reused as tail flags / positions)
+    void *temp;
+    size_t temp_bytes;
+    adsb_track_point *points;    // [n], frame order
+    adsb_aircraft_record *aircraft; // [max_aircraft], ascending ICAO
+    uint32_t max_aircraft;
+    uint64_t *n_aircraft;        // device word
+};
+size_t track_sort_temp_bytes(size_t n);
+hipError_t launch_track(hipStream_t s, const TrackArgs &a);
+
 // test / measurement kernels
 hipError_t launch_magnitudes(hipStream_t s, int sample_type, int mag_mode, const void *iq,
                              size_t n, uint16_t *out);

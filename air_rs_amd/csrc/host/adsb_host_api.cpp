@@ -3,8 +3,11 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <unordered_map>
 #include <thread>
 
+#include "adsb_aircraft.hpp"
 #include "adsb_threads.hpp"
 
 using namespace air_rs_amd;
@@ -155,3 +158,63 @@ extern "C" int adsb_save_c16(const char *path, const int16_t *data, size_t n_sam
 }
 
 extern "C" void adsb_free(void *p) { std::free(p); }
+
+// ---- tracker + CPR (aircraft.rs, cpr.rs) ---------------------------------------------------------------
+struct adsb_tracker {
+    std::unordered_map<uint32_t, Aircraft> aircrafts;
+};
+
+static void fill_summary(const Aircraft &a, adsb_aircraft_summary *out)
+{
+    const AircraftSummary s = a.get_summary();
+    std::memset(out, 0, sizeof(*out));
+    out->icao = s.icao;
+    std::strncpy(out->callsign, s.callsign.c_str(), 8);
+    out->altitude = s.altitude;
+    out->has_position = s.geo_position ? 1 : 0;
+    out->latitude = s.geo_position ? s.geo_position->latitude : 0.0;
+    out->longitude = s.geo_position ? s.geo_position->longitude : 0.0;
+    out->last_contact = s.last_contact;
+}
+
+extern "C" uint32_t adsb_cpr_num_zones(double latitude) { return calc_num_zones(latitude); }
+
+extern "C" int adsb_cpr_position(uint32_t even_lat, uint32_t even_lon, uint32_t odd_lat, uint32_t odd_lon,
+                                 int first_is_odd, double *latitude, double *longitude)
+{
+    if (!latitude || !longitude) return ADSB_E_ARG;
+    const auto g = calculate_geographic_position(even_lat, even_lon, odd_lat, odd_lon,
+                                                 first_is_odd ? CprFormat::Odd : CprFormat::Even);
+    if (!g) return 0;
+    *latitude = g->latitude;
+    *longitude = g->longitude;
+    return 1;
+}
+
+extern "C" adsb_tracker *adsb_tracker_create(void) { return new (std::nothrow) adsb_tracker(); }
+extern "C" void adsb_tracker_destroy(adsb_tracker *t) { delete t; }
+
+extern "C" int adsb_tracker_update(adsb_tracker *t, const uint8_t bytes[14], double time_s, adsb_aircraft_summary *out)
+{
+    if (!t || !bytes) return ADSB_E_ARG;
+    try {
+        AdsbPacket p(std::vector<uint8_t>(bytes, bytes + 14));
+        bool np = false;
+        const Aircraft a = handle_aircraft_update(p, time_s, t->aircrafts, &np);
+        if (out) fill_summary(a, out);
+        return np ? 1 : 0;
+    } catch (...) {
+        return ADSB_E_NOMEM;
+    }
+}
+
+extern "C" size_t adsb_tracker_count(const adsb_tracker *t) { return t ? t->aircrafts.size() : 0; }
+
+extern "C" int adsb_tracker_get(const adsb_tracker *t, uint32_t icao, adsb_aircraft_summary *out)
+{
+    if (!t || !out) return ADSB_E_ARG;
+    const auto it = t->aircrafts.find(icao);
+    if (it == t->aircrafts.end()) return ADSB_E_ARG;
+    fill_summary(it->second, out);
+    return ADSB_OK;
+}

@@ -54,6 +54,54 @@ def synth_slot(cfg, channel, slot):
     return bool(r), start.value, bytes(clean), bytes(sent), kind.value
 
 
+TRACK_POINT_DTYPE = np.dtype([("latitude", "<f8"), ("longitude", "<f8"), ("icao", "<u4"), ("flags", "<u4")])
+AIRCRAFT_DTYPE = np.dtype([("latitude", "<f8"), ("longitude", "<f8"), ("last_contact", "<f8"), ("icao", "<u4"),
+                           ("altitude", "<i4"), ("has_position", "<u4"), ("n_frames", "<u4"), ("callsign", "S8")])
+
+
+class Tracker:
+    """Host mirror of the reference's `HashMap<u32, Aircraft>` + handle_aircraft_update (aircraft.rs:158-165)."""
+
+    def __init__(self):
+        self._lib = L.load()
+        self._h = self._lib.adsb_tracker_create()
+
+    def update(self, frame_bytes, time_s):
+        b = np.frombuffer(bytes(frame_bytes), dtype=np.uint8).copy()
+        out = L.AdsbAircraftSummary()
+        r = self._lib.adsb_tracker_update(self._h, b.ctypes.data, float(time_s), C.byref(out))
+        if r < 0:
+            raise L.AdsbError(r, "adsb_tracker_update")
+        return bool(r), out
+
+    def get(self, icao):
+        out = L.AdsbAircraftSummary()
+        L.check(self._lib.adsb_tracker_get(self._h, icao, C.byref(out)), "adsb_tracker_get")
+        return out
+
+    def __len__(self):
+        return self._lib.adsb_tracker_count(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.adsb_tracker_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cpr_position(even_lat, even_lon, odd_lat, odd_lon, first_is_odd):
+    """cpr.rs:135-147 through the host mirror: (lat, lon) or None."""
+    lib = L.load()
+    lat, lon = C.c_double(), C.c_double()
+    r = lib.adsb_cpr_position(even_lat, even_lon, odd_lat, odd_lon, int(first_is_odd), C.byref(lat), C.byref(lon))
+    return (lat.value, lon.value) if r == 1 else None
+
+
 class AdsbDemod:
     """adsb_ctx wrapper.  ``stream`` is a hipStream_t as int (e.g. torch's current stream)."""
 
@@ -103,6 +151,18 @@ class AdsbDemod:
     def kernel(self):
         """'stream' (i8 default) or 'tiles' (i16; i8 with ADSB_KERNEL=tiles at creation)."""
         return "stream" if self._lib.adsb_debug_kernel(self._h) == 1 else "tiles"
+
+    # -- behind the channel: tracker + CPR on the device (aircraft.rs, cpr.rs) ------------------------
+    def track(self, seconds_per_sample=0.5e-6):
+        """Runs the tracker over the last (single-channel) launch's frame list.  Returns (points, aircraft):
+        structured arrays, one point per frame (frame order) and one record per ICAO (ascending)."""
+        L.check(self._lib.adsb_track_device(self._h, float(seconds_per_sample)), "adsb_track_device")
+        pts = np.zeros(max(self.max_out, 1), dtype=TRACK_POINT_DTYPE)
+        acs = np.zeros(max(self.max_out, 1), dtype=AIRCRAFT_DTYPE)
+        npts, nac = C.c_size_t(), C.c_size_t()
+        L.check(self._lib.adsb_fetch_track(self._h, pts.ctypes.data, len(pts), C.byref(npts), acs.ctypes.data,
+                                           len(acs), C.byref(nac)), "adsb_fetch_track")
+        return pts[:npts.value].copy(), acs[:min(nac.value, len(acs))].copy()
 
     def stamps(self):
         """Diagnostic builds (-DADSB_STAMPS=1): 16 shader-cycle sums of workgroup 0, last launch."""

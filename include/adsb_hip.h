@@ -168,6 +168,39 @@ int adsb_fetch_fields(adsb_ctx *ctx, adsb_packet_fields *out, size_t max_out, si
 /* Device pointer to the records (valid until the next decode on this ctx); does not synchronise. */
 int adsb_fields_device(adsb_ctx *ctx, const adsb_packet_fields **fields_dev);
 
+/*
+ * Tracker + global CPR position decode on the device: what the reference's display
+ * threads do with every AdsbPacket, `handle_aircraft_update` (src/adsb/aircraft.rs:158-165 ->
+ * Aircraft::handle_packet, aircraft.rs:48-111 -> cpr::calculate_geographic_position, cpr.rs:135-147),
+ * applied to the ordered frame list of the last single-channel launch, starting from an empty aircraft
+ * map (like the demodulation itself, no state is carried between launches).  Packet time = frame offset
+ * x seconds_per_sample (the reference stamps the wall clock; excluded from parity).  f64 arithmetic;
+ * parity with the reference is by tolerance (its own tests use 1e-4 degrees).
+ */
+#define ADSB_TRACK_NEW_POSITION 0x1u /* this frame completed an even/odd pair: latitude/longitude valid */
+typedef struct adsb_track_point {   /* one per frame, in frame order */
+    double   latitude, longitude;   /* degrees; 0 unless ADSB_TRACK_NEW_POSITION */
+    uint32_t icao;
+    uint32_t flags;
+} adsb_track_point;
+typedef struct adsb_aircraft_record { /* AircraftSummary (aircraft.rs:14-23), one per ICAO, ascending ICAO */
+    double   latitude, longitude;   /* geo_position, valid if has_position */
+    double   last_contact;          /* seconds: time of the last position message (aircraft.rs:56); NaN if none */
+    uint32_t icao;
+    int32_t  altitude;              /* feet, of the last position message; 0 if none */
+    uint32_t has_position;
+    uint32_t n_frames;              /* frames of this aircraft in the list */
+    char     callsign[8];           /* of the last identification message; zeros if none (not NUL terminated) */
+} adsb_aircraft_record;
+/* Runs adsb_decode_fields_device_async if needed, waits for the list's length, then enqueues the tracker
+ * on the ctx stream.  ADSB_E_ARG for multi-channel launches. */
+int adsb_track_device(adsb_ctx *ctx, double seconds_per_sample);
+/* Waits and copies: up to max_points per-frame points (frame order) and up to max_aircraft records
+ * (ascending ICAO); either array may be NULL with a zero count.  *n_aircraft is the number of distinct
+ * ICAO addresses in the list even if fewer records were copied. */
+int adsb_fetch_track(adsb_ctx *ctx, adsb_track_point *points, size_t max_points, size_t *n_points,
+                     adsb_aircraft_record *aircraft, size_t max_aircraft, size_t *n_aircraft);
+
 /* The stream the ctx enqueues on (hipStream_t as void*). */
 void *adsb_stream(adsb_ctx *ctx);
 

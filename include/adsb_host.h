@@ -71,6 +71,36 @@ int adsb_pipeline_playback_carry(adsb_ctx *ctx, int sample_type, const void *dat
                                  size_t chunk_len, adsb_frame *frames, size_t max_frames,
                                  size_t *n_frames, uint64_t *n_buffers);
 
+
+/* ---- behind the channel: tracker + CPR ------------------------------------------- */
+
+/* cpr.rs:39-54 calc_num_zones; cpr.rs:135-147 calculate_geographic_position (returns 1 = Some, 0 = None).
+ * first_is_odd: the OLDER message's CPR format (`first`), 0 = Even, 1 = Odd. */
+uint32_t adsb_cpr_num_zones(double latitude);
+int adsb_cpr_position(uint32_t even_lat, uint32_t even_lon, uint32_t odd_lat, uint32_t odd_lon, int first_is_odd,
+                      double *latitude, double *longitude);
+
+/* AircraftSummary (aircraft.rs:14-23) */
+typedef struct adsb_aircraft_summary {
+    uint32_t icao;
+    char     callsign[9];   /* "" while None */
+    int32_t  altitude;
+    int32_t  has_position;  /* geo_position.is_some() */
+    double   latitude, longitude;
+    double   last_contact;  /* seconds on the caller's clock (the reference: wall clock) */
+} adsb_aircraft_summary;
+
+/* The `HashMap<u32, Aircraft>` of the display threads + handle_aircraft_update (aircraft.rs:158-165). */
+typedef struct adsb_tracker adsb_tracker;
+adsb_tracker *adsb_tracker_create(void);
+void adsb_tracker_destroy(adsb_tracker *t);
+/* Feeds one packet (time_s stands in for AdsbPacket::time_processed).  Returns 1 if the packet produced a
+ * new geographic position, 0 if not, < 0 on error; *out (optional) = the aircraft's summary afterwards. */
+int adsb_tracker_update(adsb_tracker *t, const uint8_t bytes[14], double time_s, adsb_aircraft_summary *out);
+size_t adsb_tracker_count(const adsb_tracker *t);
+/* Summary of one aircraft; ADSB_E_ARG if the ICAO address has not been seen. */
+int adsb_tracker_get(const adsb_tracker *t, uint32_t icao, adsb_aircraft_summary *out);
+
 /* utils.rs:22-43 / 6-20.  adsb_load_c16 allocates *data with malloc (free with adsb_free). */
 int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples);
 int adsb_save_c16(const char *path, const int16_t *data, size_t n_samples);

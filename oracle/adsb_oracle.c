@@ -375,3 +375,215 @@ size_t oracle_packet_display(const oracle_packet *p, const char *time_str, char 
     if (dst && cap > n) memcpy(dst, tmp, n + 1);
     return n;
 }
+
+/* ======================================================================================== */
+/* src/adsb/cpr.rs                                                                          */
+/* ======================================================================================== */
+
+#define ORACLE_PI 3.14159265358979323846264338327950288 /* std::f64::consts::PI */
+static const double NUM_ZONES = 15.0;                   /* cpr.rs:19 */
+
+static double convert_cpr_to_float(uint32_t cpr)        /* cpr.rs:22-25 */
+{
+    return (double)cpr / 131072.0;
+}
+
+static double normalize_longitude(double lon)           /* cpr.rs:27-31 */
+{
+    while (lon < -180.0) lon += 360.0;
+    while (lon > 180.0) lon -= 360.0;
+    return lon;
+}
+
+/* `x.floor() as u32`: Rust float->int casts saturate and map NaN to 0 */
+static uint32_t floor_as_u32(double x)
+{
+    double f = floor(x);
+    if (!(f >= 0.0)) return 0u;
+    if (f >= 4294967295.0) return 4294967295u;
+    return (uint32_t)f;
+}
+
+uint32_t oracle_calc_num_zones(double lat)               /* cpr.rs:39-54 */
+{
+    if (lat == 0.0) return 59;
+    else if (lat == 87.0 || lat == -87.0) return 2;
+    else if (lat < -87.0 || lat > 87.0) return 1;
+    const double pi = ORACLE_PI;
+    double int1 = 1.0 - cos(pi / (2.0 * NUM_ZONES));
+    double int2 = cos(pi / 180.0 * lat);
+    double int3 = (2.0 * pi) / acos(1.0 - (int1 / (int2 * int2)));
+    return floor_as_u32(int3);
+}
+
+void oracle_calculate_latitude(uint32_t even_cpr_lat_u, uint32_t odd_cpr_lat_u, int first_is_odd, double out[3])
+{                                                        /* cpr.rs:63-88 */
+    const double EVEN_LAT_DIVISIONS = 360.0 / (4.0 * NUM_ZONES);
+    const double ODD_LAT_DIVISIONS = 360.0 / (4.0 * NUM_ZONES - 1.0);
+    double even_cpr_lat = convert_cpr_to_float(even_cpr_lat_u);
+    double odd_cpr_lat = convert_cpr_to_float(odd_cpr_lat_u);
+    double latitude_index = floor(59.0 * even_cpr_lat - 60.0 * odd_cpr_lat + 0.5);
+    /* Rust's % on f64 is fmod (result takes the sign of the dividend) */
+    double even_latitude = EVEN_LAT_DIVISIONS * (fmod(latitude_index, 60.0) + even_cpr_lat);
+    double odd_latitude = ODD_LAT_DIVISIONS * (fmod(latitude_index, 59.0) + odd_cpr_lat);
+    /* "Use the newest format to determine the latitude": first Even -> odd, first Odd -> even */
+    double latitude = first_is_odd ? even_latitude : odd_latitude;
+    if (latitude > 270.0) latitude -= 360.0;
+    out[0] = latitude;
+    out[1] = even_latitude;
+    out[2] = odd_latitude;
+}
+
+double oracle_calculate_longitude(uint32_t even_cpr_long, uint32_t odd_cpr_long, double latitude, int first_is_odd)
+{                                                        /* cpr.rs:90-127 */
+    double lon_cpr_e = convert_cpr_to_float(even_cpr_long);
+    double lon_cpr_o = convert_cpr_to_float(odd_cpr_long);
+    uint32_t nl = oracle_calc_num_zones(latitude);
+    uint32_t nz = first_is_odd ? oracle_calc_num_zones(latitude)          /* later is even */
+                               : oracle_calc_num_zones(latitude - 1.0);   /* later is odd (sic: latitude - 1.0) */
+    if (nz < 1) nz = 1;                                                   /* .max(1) */
+    double num_zones = (double)nz;
+    double divisions = 360.0 / num_zones;
+    /* (nl - 1) as f64: u32 arithmetic; nl >= 1 on every path of calc_num_zones except NaN -> 0, where the
+     * reference would overflow (panic in debug, wrap in release); wrap like release */
+    double m = floor(lon_cpr_e * (double)(uint32_t)(nl - 1u) - lon_cpr_o * (double)nl + 0.5);
+    double longitude = first_is_odd ? divisions * (fmod(m, num_zones) + lon_cpr_e)
+                                    : divisions * (fmod(m, num_zones) + lon_cpr_o);
+    return normalize_longitude(longitude);
+}
+
+int oracle_calculate_geographic_position(uint32_t even_lat, uint32_t even_lon, uint32_t odd_lat, uint32_t odd_lon,
+                                         int first_is_odd, double *latitude, double *longitude)
+{                                                        /* cpr.rs:135-147 */
+    double l[3];
+    oracle_calculate_latitude(even_lat, odd_lat, first_is_odd, l);
+    if (oracle_calc_num_zones(l[1]) != oracle_calc_num_zones(l[2])) return 0; /* (the reference also prints) */
+    *longitude = oracle_calculate_longitude(even_lon, odd_lon, l[0], first_is_odd);
+    *latitude = l[0];
+    return 1;
+}
+
+/* ======================================================================================== */
+/* src/adsb/aircraft.rs                                                                     */
+/* ======================================================================================== */
+
+typedef struct {
+    uint32_t icao;
+    int has_callsign;
+    char callsign[9];
+    int32_t altitude;
+    int has_geo;
+    double lat, lon;
+    double last_contact;
+    int has_odd, has_even;               /* last_odd_packet / last_even_packet */
+    uint32_t odd_lat, odd_lon, even_lat, even_lon;
+    double odd_processed, even_processed;
+} oracle_aircraft;
+
+struct oracle_tracker {
+    oracle_aircraft *a;
+    size_t n, cap;
+};
+
+oracle_tracker *oracle_tracker_create(void)
+{
+    return (oracle_tracker *)calloc(1, sizeof(oracle_tracker));
+}
+
+void oracle_tracker_destroy(oracle_tracker *t)
+{
+    if (!t) return;
+    free(t->a);
+    free(t);
+}
+
+static void aircraft_summary(const oracle_aircraft *a, oracle_aircraft_summary *s)   /* aircraft.rs:142-152 */
+{
+    memset(s, 0, sizeof(*s));
+    s->icao = a->icao;
+    if (a->has_callsign) memcpy(s->callsign, a->callsign, 9);
+    s->altitude = a->altitude;
+    s->has_position = a->has_geo;
+    s->latitude = a->lat;
+    s->longitude = a->lon;
+    s->last_contact = a->last_contact;
+}
+
+/* Aircraft::handle_packet (aircraft.rs:48-111); returns 1 when geo_position was (re)computed */
+static int aircraft_handle_packet(oracle_aircraft *self, const oracle_packet *msg, double time_processed)
+{
+    if (msg->icao != self->icao) return 0;                                   /* :49-51 */
+    if (msg->msg_kind == ORACLE_MSG_AIRCRAFT_POSITION) {
+        self->altitude = msg->altitude;                                      /* :55 */
+        self->last_contact = time_processed;                                 /* :56 */
+        uint32_t cpr_odd_lat, cpr_odd_lon, cpr_even_lat, cpr_even_lon;
+        int first_is_odd;
+        if (!msg->cpr_odd) {                                                 /* CprFormat::Even, :63-77 */
+            self->has_even = 1;
+            self->even_lat = msg->cpr_latitude;
+            self->even_lon = msg->cpr_longitude;
+            self->even_processed = time_processed;
+            if (!self->has_odd) return 0;
+            if (fabs(time_processed - self->odd_processed) > 10.0) return 0; /* :68-70 */
+            cpr_odd_lat = self->odd_lat; cpr_odd_lon = self->odd_lon;
+            cpr_even_lat = msg->cpr_latitude; cpr_even_lon = msg->cpr_longitude;
+            first_is_odd = 1;
+        } else {                                                             /* CprFormat::Odd, :79-94 */
+            self->has_odd = 1;
+            self->odd_lat = msg->cpr_latitude;
+            self->odd_lon = msg->cpr_longitude;
+            self->odd_processed = time_processed;
+            if (!self->has_even) return 0;
+            if (fabs(time_processed - self->even_processed) > 10.0) return 0;
+            cpr_odd_lat = msg->cpr_latitude; cpr_odd_lon = msg->cpr_longitude;
+            cpr_even_lat = self->even_lat; cpr_even_lon = self->even_lon;
+            first_is_odd = 0;
+        }
+        double lat, lon;
+        if (oracle_calculate_geographic_position(cpr_even_lat, cpr_even_lon, cpr_odd_lat, cpr_odd_lon,
+                                                 first_is_odd, &lat, &lon)) { /* :97-102 */
+            self->has_geo = 1;
+            self->lat = lat;
+            self->lon = lon;
+            return 1;
+        }
+        return 0;
+    } else if (msg->msg_kind == ORACLE_MSG_AIRCRAFT_ID) {                    /* :105-107 */
+        self->has_callsign = 1;
+        memcpy(self->callsign, msg->callsign, 9);
+    }
+    return 0;                                                                /* Uknown: :108-110 */
+}
+
+int oracle_tracker_update(oracle_tracker *t, const uint8_t bytes[14], double time_s, oracle_aircraft_summary *out)
+{                                                                            /* aircraft.rs:158-165 */
+    oracle_packet pk;
+    oracle_packet_new(bytes, &pk);
+    size_t k = 0;
+    while (k < t->n && t->a[k].icao != pk.icao) ++k;                         /* HashMap entry(icao) */
+    if (k == t->n) {                                                         /* or_insert(Aircraft::new(icao)) */
+        if (t->n == t->cap) {
+            size_t nc = t->cap ? 2 * t->cap : 64;
+            oracle_aircraft *na = (oracle_aircraft *)realloc(t->a, nc * sizeof(*na));
+            if (!na) return -1;
+            t->a = na;
+            t->cap = nc;
+        }
+        memset(&t->a[k], 0, sizeof(t->a[k]));
+        t->a[k].icao = pk.icao;
+        t->a[k].last_contact = NAN;
+        t->n++;
+    }
+    int r = aircraft_handle_packet(&t->a[k], &pk, time_s);
+    if (out) aircraft_summary(&t->a[k], out);
+    return r;
+}
+
+size_t oracle_tracker_count(const oracle_tracker *t) { return t->n; }
+
+int oracle_tracker_get(const oracle_tracker *t, size_t index, oracle_aircraft_summary *out)
+{
+    if (index >= t->n) return -1;
+    aircraft_summary(&t->a[index], out);
+    return 0;
+}

@@ -118,6 +118,44 @@ void oracle_packet_new(const uint8_t bytes[14], oracle_packet *p);
  * Returns the number of bytes written (excluding NUL), or the needed size if cap too small. */
 size_t oracle_packet_display(const oracle_packet *p, const char *time_str, char *dst, size_t cap);
 
+
+/* ---- cpr.rs: global CPR decode (f64; parity by tolerance: the reference's own tests use 1e-4 deg) --- */
+
+/* cpr.rs:39-54 calc_num_zones */
+uint32_t oracle_calc_num_zones(double lat);
+/* cpr.rs:63-88 calculate_latitude: out[0] = selected latitude, out[1] = even, out[2] = odd.
+ * first_is_odd: the OLDER message's format (CprFormat `first`): 0 = Even, 1 = Odd. */
+void oracle_calculate_latitude(uint32_t even_cpr_lat, uint32_t odd_cpr_lat, int first_is_odd, double out[3]);
+/* cpr.rs:90-127 calculate_longitude */
+double oracle_calculate_longitude(uint32_t even_cpr_long, uint32_t odd_cpr_long, double latitude, int first_is_odd);
+/* cpr.rs:135-147 calculate_geographic_position: returns 1 for Some (lat/lon written), 0 for None */
+int oracle_calculate_geographic_position(uint32_t even_lat, uint32_t even_lon, uint32_t odd_lat, uint32_t odd_lon,
+                                         int first_is_odd, double *latitude, double *longitude);
+
+/* ---- aircraft.rs: per-ICAO tracker (Aircraft::handle_packet + handle_aircraft_update) ---------- */
+
+typedef struct {
+    uint32_t icao;
+    char     callsign[9];     /* "" while None (aircraft.rs:119-126) */
+    int32_t  altitude;
+    int32_t  has_position;    /* geo_position.is_some() */
+    double   latitude, longitude;
+    double   last_contact;    /* seconds; the reference stores a wall-clock DateTime (set on Position messages
+                                 only, aircraft.rs:56); NaN until the first one here */
+} oracle_aircraft_summary;
+
+typedef struct oracle_tracker oracle_tracker;
+oracle_tracker *oracle_tracker_create(void);
+void oracle_tracker_destroy(oracle_tracker *t);
+/* aircraft.rs:158-165 handle_aircraft_update: `time_s` stands in for packet.time_processed (the reference
+ * takes the wall clock at AdsbPacket::new; here the caller supplies seconds, e.g. sample offset / 2e6).
+ * Writes the updated aircraft's summary to *out (may be NULL).  Returns 1 if this packet produced a new
+ * geographic position, 0 otherwise. */
+int oracle_tracker_update(oracle_tracker *t, const uint8_t bytes[14], double time_s, oracle_aircraft_summary *out);
+size_t oracle_tracker_count(const oracle_tracker *t);
+/* aircraft in order of first appearance */
+int oracle_tracker_get(const oracle_tracker *t, size_t index, oracle_aircraft_summary *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,9 +36,14 @@ def lib():
 
 
 def _have_gpu():
+    # Ask the product library itself (adsb_create fails with ADSB_E_NODEVICE without a HIP device).  Not
+    # torch.cuda.is_available(): the torch wheel carries its own HIP runtime, and initialising it AFTER
+    # libadsb_hip.so has loaded the system one (CPU-tier tests of the same session do) leaves the library
+    # without a device.
     try:
-        import torch
-        return torch.cuda.is_available()
+        import air_rs_amd
+        air_rs_amd.AdsbDemod(max_samples=1024, max_out=16).close()
+        return True
     except Exception:
         return False
 

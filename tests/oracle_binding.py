@@ -19,6 +19,48 @@ class OraclePacket(C.Structure):
                 ("raw_msg", C.c_uint8 * 10)]
 
 
+class OracleAircraftSummary(C.Structure):
+    _fields_ = [("icao", C.c_uint32), ("callsign", C.c_char * 9), ("altitude", C.c_int32),
+                ("has_position", C.c_int32), ("latitude", C.c_double), ("longitude", C.c_double),
+                ("last_contact", C.c_double)]
+
+    def as_tuple(self):
+        return (self.icao, self.callsign.decode(), self.altitude, bool(self.has_position),
+                self.latitude if self.has_position else None, self.longitude if self.has_position else None,
+                self.last_contact)
+
+
+class OracleTracker:
+    """aircraft.rs: HashMap<u32, Aircraft> + handle_aircraft_update, restated in oracle/adsb_oracle.c."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = lib.oracle_tracker_create()
+
+    def update(self, frame_bytes, time_s):
+        b = np.frombuffer(bytes(frame_bytes), dtype=np.uint8).copy()
+        out = OracleAircraftSummary()
+        r = self.lib.oracle_tracker_update(self.h, b.ctypes.data, float(time_s), C.byref(out))
+        assert r >= 0
+        return bool(r), out
+
+    def aircraft(self):
+        res = []
+        for k in range(self.lib.oracle_tracker_count(self.h)):
+            s = OracleAircraftSummary()
+            assert self.lib.oracle_tracker_get(self.h, k, C.byref(s)) == 0
+            res.append(s)
+        return res
+
+    def close(self):
+        if self.h:
+            self.lib.oracle_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Oracle:
     E_SHORT = -1
 
@@ -50,6 +92,24 @@ class Oracle:
         L.oracle_packet_new.argtypes = [C.c_void_p, C.POINTER(OraclePacket)]
         L.oracle_packet_display.argtypes = [C.POINTER(OraclePacket), C.c_char_p, C.c_char_p, C.c_size_t]
         L.oracle_packet_display.restype = C.c_size_t
+        # cpr.rs / aircraft.rs
+        L.oracle_calc_num_zones.argtypes = [C.c_double]
+        L.oracle_calc_num_zones.restype = C.c_uint32
+        L.oracle_calculate_latitude.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+        L.oracle_calculate_latitude.restype = None
+        L.oracle_calculate_longitude.argtypes = [C.c_uint32, C.c_uint32, C.c_double, C.c_int]
+        L.oracle_calculate_longitude.restype = C.c_double
+        L.oracle_calculate_geographic_position.argtypes = [C.c_uint32] * 4 + [C.c_int, C.POINTER(C.c_double),
+                                                                              C.POINTER(C.c_double)]
+        L.oracle_calculate_geographic_position.restype = C.c_int
+        L.oracle_tracker_create.restype = C.c_void_p
+        L.oracle_tracker_destroy.argtypes = [C.c_void_p]
+        L.oracle_tracker_update.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(OracleAircraftSummary)]
+        L.oracle_tracker_update.restype = C.c_int
+        L.oracle_tracker_count.argtypes = [C.c_void_p]
+        L.oracle_tracker_count.restype = C.c_size_t
+        L.oracle_tracker_get.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(OracleAircraftSummary)]
+        L.oracle_tracker_get.restype = C.c_int
 
     # utils.rs:46-52
     def get_magnitude(self, iq_i16):
@@ -132,3 +192,24 @@ class Oracle:
         buf = C.create_string_buffer(2048)
         n = self.lib.oracle_packet_display(C.byref(p), time_text.encode(), buf, 2048)
         return buf.value.decode()[:n]
+
+    # cpr.rs
+    def calc_num_zones(self, lat):
+        return self.lib.oracle_calc_num_zones(float(lat))
+
+    def calculate_latitude(self, even, odd, first_is_odd):
+        out = (C.c_double * 3)()
+        self.lib.oracle_calculate_latitude(even, odd, int(first_is_odd), out)
+        return tuple(out)
+
+    def calculate_longitude(self, even, odd, latitude, first_is_odd):
+        return self.lib.oracle_calculate_longitude(even, odd, float(latitude), int(first_is_odd))
+
+    def geographic_position(self, even_lat, even_lon, odd_lat, odd_lon, first_is_odd):
+        lat, lon = C.c_double(), C.c_double()
+        ok = self.lib.oracle_calculate_geographic_position(even_lat, even_lon, odd_lat, odd_lon, int(first_is_odd),
+                                                           C.byref(lat), C.byref(lon))
+        return (lat.value, lon.value) if ok else None
+
+    def tracker(self):
+        return OracleTracker(self.lib)
