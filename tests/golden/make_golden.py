@@ -91,6 +91,29 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), iq=iq, frames=frames)
         print(f"{name:18s} {iq.shape[0]:6d} samples ({iq.dtype}) -> {n} frames")
 
+    # 7. behind the channel (aircraft.rs / cpr.rs): a time-ordered frame list and what the oracle's tracker
+    #    makes of it -- per frame: did it complete an even/odd pair, and the position; per aircraft: the summary
+    from tests.traffic import random_traffic
+    traffic = random_traffic(orc, seed=77, n_aircraft=12, n_frames=600, span_s=45.0)
+    trk = orc.tracker()
+    new = np.zeros(len(traffic), dtype=np.uint8)
+    pos = np.zeros((len(traffic), 2), dtype=np.float64)
+    for k, (t, fr) in enumerate(traffic):
+        got, s = trk.update(fr, t)
+        new[k] = got
+        if got:
+            pos[k] = (s.latitude, s.longitude)
+    table = sorted(trk.aircraft(), key=lambda s: s.icao)
+    np.savez_compressed(
+        os.path.join(OUT, "tracker_traffic.npz"),
+        times=np.array([t for t, _ in traffic]), frames=np.frombuffer(b"".join(fr for _, fr in traffic), dtype=np.uint8).reshape(-1, 14),
+        new_position=new, position=pos,
+        icao=np.array([s.icao for s in table], dtype=np.uint32), callsign=np.array([s.callsign for s in table]),
+        altitude=np.array([s.altitude for s in table], dtype=np.int32),
+        has_position=np.array([s.has_position for s in table], dtype=np.uint8),
+        latitude=np.array([s.latitude for s in table]), longitude=np.array([s.longitude for s in table]))
+    print(f"tracker_traffic    {len(traffic)} frames, {len(table)} aircraft, {int(new.sum())} positions")
+
 
 if __name__ == "__main__":
     main()

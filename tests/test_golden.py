@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+# IQ fixtures (tracker_traffic.npz is a frame-list fixture: tests/test_tracker.py)
+FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if "tracker" not in os.path.basename(f))
 REF_FRAMES = ["8d7c6b3020293532d70820fc8090", "8d7c6b30581304f388bb4455896f", "8d40621d58c386435cc412692ad6",
               "8d40621d58c382d690c8ac2863a7", "8d7c6b30580d107903b3cabf62ab", "8d7c6b30580d24eeaebb2dfea5bb",
               "8d406b902015a678d4d220aa4bda"]

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import air_rs_amd as A
+from tests.traffic import random_traffic
 
 # the reference's tests compare positions with 1e-4 degrees (cpr.rs:159,187; aircraft.rs:209-210,260-261)
 REF_TOL = 1e-4
@@ -80,61 +81,6 @@ def test_host_cpr_equals_oracle(oracle):
         assert lib.adsb_cpr_num_zones(la) == oracle.calc_num_zones(la)
 
 
-def position_frame(oracle, icao, odd, cpr_lat, cpr_lon, alt_code=0x3A8, tc=11):
-    """A DF17 airborne-position frame (msgs.rs:70-102 layout) with a correct CRC (crc.rs:10-40)."""
-    me = bytearray(7)
-    me[0] = (tc << 3)
-    me[1] = (alt_code >> 4) & 0xFF          # 12-bit altitude code: bits 7..1 of m1 + q bit, high nibble of m2
-    me[2] = ((alt_code & 0xF) << 4) | (int(odd) << 2) | ((cpr_lat >> 15) & 0x3)
-    me[3] = (cpr_lat >> 7) & 0xFF
-    me[4] = ((cpr_lat & 0x7F) << 1) | ((cpr_lon >> 16) & 0x1)
-    me[5] = (cpr_lon >> 8) & 0xFF
-    me[6] = cpr_lon & 0xFF
-    data = bytes([0x8D, (icao >> 16) & 0xFF, (icao >> 8) & 0xFF, icao & 0xFF]) + bytes(me)
-    crc = oracle.get_adsb_crc(data)
-    return data + bytes([(crc >> 16) & 0xFF, (crc >> 8) & 0xFF, crc & 0xFF])
-
-
-def ident_frame(oracle, icao, chars6):
-    """A DF17 identification frame (TC 4): eight 6-bit characters (msgs.rs:150-177)."""
-    bits = 0
-    for c in chars6:
-        bits = (bits << 6) | (int(c) & 0x3F)
-    me = bytes([4 << 3]) + bits.to_bytes(6, "big")
-    data = bytes([0x8D, (icao >> 16) & 0xFF, (icao >> 8) & 0xFF, icao & 0xFF]) + me
-    crc = oracle.get_adsb_crc(data)
-    return data + bytes([(crc >> 16) & 0xFF, (crc >> 8) & 0xFF, crc & 0xFF])
-
-
-def random_traffic(oracle, seed, n_aircraft=40, n_frames=3000, span_s=60.0):
-    """A time-ordered list of (time_s, frame) from a few aircraft: mostly position messages with plausible
-    (consistent) even/odd CPR pairs, some identification messages, some long silences."""
-    rng = np.random.default_rng(seed)
-    icaos = rng.choice(np.arange(0x400000, 0x800000), size=n_aircraft, replace=False)
-    lat = rng.uniform(-80, 80, n_aircraft)
-    lon = rng.uniform(-180, 180, n_aircraft)
-    out = []
-    times = np.sort(rng.uniform(0, span_s, n_frames))
-    for t in times:
-        a = int(rng.integers(0, n_aircraft))
-        if rng.random() < 0.1:
-            out.append((float(t), ident_frame(oracle, int(icaos[a]), list(rng.integers(1, 27, size=8)))))
-            continue
-        odd = bool(rng.integers(0, 2))
-        # CPR encode (the inverse of cpr.rs, ICAO Doc 9871): enough to make pairs decode to sensible places
-        dlat = 360.0 / (59 if odd else 60)
-        yz = math.floor(131072 * ((lat[a] % dlat) / dlat) + 0.5)
-        rlat = dlat * (yz / 131072 + math.floor(lat[a] / dlat))
-        nl = max(oracle.calc_num_zones(rlat) - (1 if odd else 0), 1)
-        dlon = 360.0 / nl
-        xz = math.floor(131072 * ((lon[a] % dlon) / dlon) + 0.5)
-        out.append((float(t), position_frame(oracle, int(icaos[a]), odd, int(yz) & 0x1FFFF, int(xz) & 0x1FFFF,
-                                             alt_code=int(rng.integers(0, 1 << 12)))))
-        lat[a] += rng.normal(0, 0.002)
-        lon[a] += rng.normal(0, 0.002)
-    return out
-
-
 def test_host_tracker_equals_oracle(oracle):
     traffic = random_traffic(oracle, seed=9)
     ot, ht = oracle.tracker(), A.Tracker()
@@ -151,6 +97,30 @@ def test_host_tracker_equals_oracle(oracle):
     for so in ot.aircraft():
         sh = ht.get(so.icao)
         assert so.callsign == sh.callsign and so.altitude == sh.altitude and so.has_position == sh.has_position
+
+
+def test_golden_tracker_fixture(oracle):
+    """tests/golden/tracker_traffic.npz (written by make_golden.py from the oracle): the oracle and the C++ host
+    mirror both reproduce it -- per-frame new-position flags, positions, the aircraft table."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tracker_traffic.npz"))
+    assert len(z["frames"]) == 600 and int(z["new_position"].sum()) > 100
+    ot, ht = oracle.tracker(), A.Tracker()
+    for k, (t, fr) in enumerate(zip(z["times"], z["frames"])):
+        new_o, so = ot.update(bytes(fr), float(t))
+        new_h, sh = ht.update(bytes(fr), float(t))
+        assert new_o == new_h == bool(z["new_position"][k])
+        if new_o:
+            assert (so.latitude, so.longitude) == tuple(z["position"][k])
+            assert (sh.latitude, sh.longitude) == pytest.approx(tuple(z["position"][k]), abs=1e-12)
+    table = sorted(ot.aircraft(), key=lambda s: s.icao)
+    assert [s.icao for s in table] == list(z["icao"])
+    for s, cs, alt, hp, la, lo in zip(table, z["callsign"], z["altitude"], z["has_position"], z["latitude"], z["longitude"]):
+        sh = ht.get(s.icao)
+        assert s.callsign == bytes(cs) == sh.callsign and s.altitude == alt == sh.altitude
+        assert bool(s.has_position) == bool(hp) == bool(sh.has_position)
+        if hp:
+            assert (s.latitude, s.longitude) == (la, lo)
 
 
 @pytest.mark.gpu
