@@ -185,6 +185,22 @@ __device__ __forceinline__ uint2 lookup_pack(const uint32_t m[8])
     return make_uint2(__builtin_amdgcn_perm(p1, p0, 0x06040200u), __builtin_amdgcn_perm(p3, p2, 0x06040200u));
 }
 
+// Table indices with the 4-instruction-per-dword form (shift, bitop3, and, shift): the intermediate is made
+// opaque so that hipcc does not re-derive the low index from the raw dword with a fifth instruction.
+// (The packing stays hipcc's 3 instructions per 4 bytes: the d16 byte loads that would deliver two
+// magnitudes per register do not preserve the other half on this part -- SRAM ECC -- measured: wrong data.)
+__device__ __forceinline__ void lookup_indices8_lean(u32x4 v, uint32_t idx[8])
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t x = w[d] ^ ((w[d] >> 6) & 0x03FC03FCu);
+        asm("" : "+v"(x));
+        idx[2 * d] = x & 0xFFFFu;
+        idx[2 * d + 1] = x >> 16;
+    }
+}
+
 // Barrier schedule shared by the two roles (every wave executes the same sequence of s_barrier):
 //   P1  table in LDS                      P2  tile 0 converted
 //   per round i = 0 .. n_my:   D(i)  inside the gate of tile i (the last round has no gate: bare D)
@@ -280,7 +296,7 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
         for (int it = 0; it < kSIters - 1; ++it) {
             uint32_t idx[8], m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             asm volatile("s_waitcnt vmcnt(" ADSB_STR(ADSB_STREAM_VMCNT) ")" : "+v"(raw[it]));
-            lookup_indices8(raw[it], idx);
+            lookup_indices8_lean(raw[it], idx);
             reload_in_place(raw[it], idx, (uint32_t)it * (kSLookupThreads * 16) + tg * 16, rn);
             if (!ADSB_ABL_NOLOOKUP) lookup_reads8(lut, idx, m);
             if (it > 0 && !ADSB_ABL_NOLOOKUP)
