@@ -13,6 +13,32 @@ from tests.traffic import random_traffic
 REF_TOL = 1e-4
 
 
+def test_kats_json_matches_oracle(oracle):
+    """tests/golden/reference_kats.json carries the same reference vectors (transcribed values)."""
+    import json, os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+    for lat, want in k["cpr"]["zones"]["cases"]:
+        assert oracle.calc_num_zones(lat) == want
+    c = k["cpr"]["latitude"]
+    assert abs(oracle.calculate_latitude(c["even_cpr_lat"], c["odd_cpr_lat"], c["first"] == "Odd")[0] - c["latitude"]) < c["tolerance"]
+    c = k["cpr"]["longitude"]
+    assert oracle.calculate_longitude(c["even_cpr_long"], c["odd_cpr_long"], c["latitude"], c["first"] == "Odd") == c["code_yields"]
+    for case in k["aircraft"]:
+        t = oracle.tracker()
+        for n, h in enumerate(case["frames"]):
+            _, s = t.update(bytes.fromhex(h), 0.5 * n)
+        if "callsign" in case:
+            assert s.callsign.decode() == case["callsign"]
+        if "altitude" in case:
+            assert s.altitude == case["altitude"]
+        if "latitude" in case:
+            assert abs(s.latitude - case["latitude"]) < case["tolerance"]
+        if "longitude" in case:
+            assert abs(s.longitude - case["longitude"]) < case["tolerance"]
+        if "longitude_code_yields" in case:
+            assert s.longitude == case["longitude_code_yields"]
+
+
 def test_cpr_reference_kats(oracle):
     # cpr.rs:152-160 test_latitude_calculation
     lat = oracle.calculate_latitude(93000, 74158, first_is_odd=True)
