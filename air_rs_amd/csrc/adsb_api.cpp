@@ -98,11 +98,11 @@ struct adsb_ctx {
         if (e_ != hipSuccess) return (int)e_;      \
     } while (0)
 
-static uint32_t tiles_for(uint64_t n_samples)
+static uint32_t tiles_for(uint64_t n_samples, int sample_type)
 {
     if (n_samples <= (uint64_t)kWindow) return 0;
-    uint64_t n_off = n_samples - kWindow;
-    return (uint32_t)((n_off + kTile - 1) / kTile);
+    const uint64_t n_off = n_samples - kWindow, tile = (uint64_t)adsbk::tile_offsets(sample_type);
+    return (uint32_t)((n_off + tile - 1) / tile);
 }
 
 extern "C" const char *adsb_strerror(int code)
@@ -174,7 +174,7 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     if (!c) return ADSB_E_NOMEM;
     c->cfg = *cfg;
     c->bps = cfg->sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
-    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples) * cfg->max_channels;
+    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type) * cfg->max_channels;
     if (tiles == 0) tiles = 1;
     if (tiles * adsbk::kQuota + cfg->max_out + kTile > 0xFFFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
     c->n_tiles_max = (uint32_t)tiles;
@@ -360,7 +360,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_channels = n_channels;
     c->last_samples = n_samples;
     c->last_stride = channel_stride;
-    c->last_tpc = tiles_for(n_samples);
+    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type);
     c->last_tiles = c->last_tpc * n_channels;
     c->launched = true;
     c->fields_current = false;

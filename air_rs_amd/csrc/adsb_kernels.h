@@ -17,6 +17,19 @@ constexpr int kRun = ADSB_KRUN; // consecutive offsets one lane slides over, per
 constexpr int kTile = 2 * kThreads * kRun; // offsets owned by one workgroup (32768 at kRun 64)
 constexpr int kHalo = 256;      // >= 239 extra samples so PPM never leaves the tile; 16-aligned
 constexpr int kMag = kTile + kHalo;
+// CS16 input keeps u16 magnitudes in LDS: with the i8 tile (32768 offsets, 66 KB) only two workgroups fit a
+// CU -- two waves per SIMD, far too few to hide the gate's latencies -- so i16 tiles are half as long
+// (runs of 32 offsets, 33 KB, four workgroups per CU).
+#ifndef ADSB_KRUN_I16
+#define ADSB_KRUN_I16 32
+#endif
+constexpr int kRunI16 = ADSB_KRUN_I16;
+template <int ST> struct TileCfg {
+    static constexpr int kRunT = ST == ADSB_SAMPLE_I8 ? kRun : kRunI16;
+    static constexpr int kTileT = 2 * kThreads * kRunT;
+    static constexpr int kMagT = kTileT + kHalo;
+};
+constexpr int tile_offsets(int sample_type) { return sample_type == ADSB_SAMPLE_I8 ? kTile : 2 * kThreads * kRunI16; }
 constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
 constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path
 constexpr int kWindow = 240;    // 16 + 112*2  (reference src/adsb.rs:98)

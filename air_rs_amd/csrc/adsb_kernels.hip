@@ -200,7 +200,7 @@ template <> struct MagT<ADSB_SAMPLE_I16> { typedef uint16_t type; };
 
 template <int ST> struct Lds {
     typedef typename MagT<ST>::type mag_t;
-    static constexpr int kMagBytes = kMag * (int)sizeof(mag_t);
+    static constexpr int kMagBytes = TileCfg<ST>::kMagT * (int)sizeof(mag_t);
     static constexpr int kOffCand = kMagBytes;                 // 2 words per run: survivor bitmap
     static constexpr int kOffList = kOffCand + 2 * kThreads * 8; // kListCap x u16
     static constexpr int kOffSyn = kOffList + kListCap * 2;    // 112 x u32
@@ -339,25 +339,26 @@ struct TilePos {
     uint64_t sample0;
     uint32_t n_valid;
 };
+template <int TILE = kTile>
 __device__ __forceinline__ TilePos tile_pos(const DemodArgs &p, uint32_t tile)
 {
     TilePos t;
     t.ch = tile / p.tiles_per_channel;
     const uint32_t tch = tile - t.ch * p.tiles_per_channel;
-    t.sample0 = (uint64_t)tch * kTile;
+    t.sample0 = (uint64_t)tch * TILE;
     const uint64_t left = (p.n_samples - kWindow) - t.sample0; // offsets 0..n-241 exist (adsb.rs:98)
-    t.n_valid = left < (uint64_t)kTile ? (uint32_t)left : (uint32_t)kTile;
+    t.n_valid = left < (uint64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
     return t;
 }
 
 // Bounds-checked descriptor over one tile's samples (+halo): reads past the channel end return 0,
 // so ragged tails need no branches.  `tile` must be wave-uniform.
-template <int BPS>
+template <int BPS, int MAG = kMag>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, const TilePos &t, bool live = true)
 {
     const char *base = (const char *)p.iq + ((uint64_t)t.ch * p.channel_stride + t.sample0) * BPS;
     const uint64_t remain = (p.n_samples - t.sample0) * BPS; // bytes to the end of this channel
-    const uint32_t nrec = remain > (uint64_t)(kMag * BPS) ? (uint32_t)(kMag * BPS) : (uint32_t)remain;
+    const uint32_t nrec = remain > (uint64_t)(MAG * BPS) ? (uint32_t)(MAG * BPS) : (uint32_t)remain;
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? (int)nrec : 0, 0x00020000);
 }
 
@@ -543,9 +544,10 @@ constexpr int kRawIters = (kMag + kThreads * 8 - 1) / (kThreads * 8); // 17 x 16
 #endif
 
 template <int ST, int MAGMODE>
-__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : 2)) void demod_tiles(DemodArgs p)
+__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4))) void demod_tiles(DemodArgs p)
 {
     typedef Lds<ST> L;
+    typedef TileCfg<ST> TC; // tile length of this sample type
     typedef typename L::mag_t mag_t;
     constexpr int BPS = (ST == ADSB_SAMPLE_I8) ? 2 : 4; // bytes per IQ sample
     constexpr int SPG = 16 / (int)sizeof(mag_t);         // magnitudes per 16-byte LDS granule
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     // workgroups -- all measured slower)
     {
         const uint32_t tile = p.tile_first + blockIdx.x;
-        const TilePos tp = tile_pos(p, tile);
+        const TilePos tp = tile_pos<TC::kTileT>(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
         if (blockIdx.x == 0 && tid == 0) p.hdr->retry = 0;
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
 
         // ---- phase 1: raw IQ -> magnitudes in LDS ---------------------------------------------
         {
-            __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<BPS>(p, tp);
+            __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<BPS, TC::kMagT>(p, tp);
             if (ST == ADSB_SAMPLE_I8) {
                 u32x4 raw[kRawIters];
                 // the last sweep only covers the halo: whole waves past it skip it (scalar branch)
@@ -598,13 +600,13 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                     }
                 }
             } else {
-                constexpr int kIters = (kMag + kThreads * 4 - 1) / (kThreads * 4); // 33
-#pragma unroll 11
+                constexpr int kIters = (TC::kMagT + kThreads * 4 - 1) / (kThreads * 4); // 17 (33 with 64-offset runs)
+#pragma unroll
                 for (int it = 0; it < kIters; ++it) {
                     uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
                     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, s * 4, 0, 0);
                     uint32_t m0 = mag_i16(v.x), m1 = mag_i16(v.y), m2 = mag_i16(v.z), m3 = mag_i16(v.w);
-                    if (s < (uint32_t)kMag)
+                    if (s < (uint32_t)TC::kMagT)
                         *reinterpret_cast<uint2 *>(mag + s) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
                 }
             }
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         __syncthreads();
 
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
-        gate_phase<ST, ADSB_GATE_GROUP, kRun, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
+        gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
         __syncthreads();
 
         // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
@@ -622,7 +624,8 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         uint32_t cnt = 0, my_first = 0;
         if (dense) {
             // dense fallback: ordered compaction of the bitmap by workgroup-wide prefix sums
-            cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
+            // bitmap: offset 32 w + b of the tile is bit b of word w; words 4*tid .. 4*tid+3 per thread
+            if (4 * tid < (uint32_t)(TC::kTileT / 32)) cw = reinterpret_cast<const u32x4 *>(cand)[tid];
             cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) +
                   __builtin_popcount(cw.w);
             uint32_t incl = cnt;
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                         const uint32_t b = __builtin_ctz(bits);
                         bits &= bits - 1;
                         if (idx >= chunk && idx < chunk + kListCap)
-                            list[idx - chunk] = (uint16_t)(((4 * tid + k) >> 1) * kRun + ((4 * tid + k) & 1) * 32 + b);
+                            list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
                         ++idx;
                     }
                 }
@@ -777,15 +780,19 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
         if (a.zero1) for (uint32_t k = gtid; k < a.n_grp1; k += gsz) a.zero1[k] = 0;
         if (a.zero2) for (uint32_t k = gtid; k < a.n_grp2; k += gsz) a.zero2[k] = 0;
     }
-    if (blockIdx.x == 0 && wave == 0 && a.write_header) {
-        const unsigned long long total = tile_prefix(a, a.n_tiles, lane); // (saturating)
-        for (uint32_t c0 = 0; c0 < a.n_channels; ++c0) {
+    // per-channel counts: one wave per channel, spread over the grid (a 64-channel batch would otherwise
+    // serialise 128 prefix sums on one wave: 50 us)
+    if (a.write_header) {
+        for (uint32_t c0 = blockIdx.x * 4 + wave; c0 < a.n_channels; c0 += gridDim.x * 4) {
             uint32_t b = tile_prefix(a, c0 * a.tiles_per_channel, lane);
             uint32_t e = tile_prefix(a, (c0 + 1) * a.tiles_per_channel, lane);
             b = b < a.max_out ? b : a.max_out;
             e = e < a.max_out ? e : a.max_out;
             if (lane == 0) a.chan_counts[c0] = e - b;
         }
+    }
+    if (blockIdx.x == 0 && wave == 0 && a.write_header) {
+        const unsigned long long total = tile_prefix(a, a.n_tiles, lane); // (saturating)
         if (lane == 0) {
             a.hdr->total_found = total;
             a.hdr->n_out = total < a.max_out ? total : a.max_out;

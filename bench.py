@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-type", choices=["i8", "i16"], default="i8",
                     help="i8 = BASELINE metric (2 B/sample); i16 = the reference's Complex<i16> (4 B/sample)")
+    ap.add_argument("--channels", type=int, default=1,
+                    help="split the per-GPU buffer into this many independent channels handled by ONE launch "
+                         "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
     ap.add_argument("--kernel", choices=["default", "tiles", "stream"], default="default",
                     help="i8 tile kernel: one workgroup per tile, or the streaming kernel (DESIGN.md section 4); "
                          "default = the library's default (ADSB_KERNEL in the environment is honoured)")
@@ -82,18 +85,26 @@ def main():
     st = A.ADSB_SAMPLE_I8 if args.sample_type == "i8" else A.ADSB_SAMPLE_I16
     bps = 2 if args.sample_type == "i8" else 4
     n = args.samples if args.sample_type == "i8" else args.samples // 2  # same bytes per GPU
+    nch = max(1, args.channels)
+    n_ch = (n // nch) & ~7                  # samples per channel (stride = length: contiguous, 16-byte aligned)
+    if nch > 1:
+        n = n_ch * nch
     cfg = A.synth_default()
     cfg_slot = cfg.slot_len
     own = n - A.WINDOW                      # offsets this rank owns
     first = rank * own                      # its slice of the long stream (240-sample read halo)
     cap = n // cfg_slot + 8192              # frame capacity: at most one frame per slot, + margin for noise
     stream = torch.cuda.current_stream()
-    dem = A.AdsbDemod(device=local_rank, sample_type=st, max_samples=n, max_out=cap,
-                      stream=stream.cuda_stream, host_staging=False)
+    dem = A.AdsbDemod(device=local_rank, sample_type=st, max_samples=n_ch if nch > 1 else n, max_out=cap,
+                      max_channels=nch, stream=stream.cuda_stream, host_staging=False)
     if st == A.ADSB_SAMPLE_I16:
         cfg.amp_shift = 6
     iq = torch.empty(n * bps, dtype=torch.int8, device="cuda")
-    dem.synth_fill_device(cfg, 0, first, n, iq.data_ptr())
+    if nch == 1:
+        dem.synth_fill_device(cfg, 0, first, n, iq.data_ptr())
+    else:
+        for c in range(nch):                # every channel is its own stream (its own generator channel)
+            dem.synth_fill_device(cfg, c, first, n_ch, iq.data_ptr() + c * n_ch * bps)
     torch.cuda.synchronize()
 
     rec = 24
@@ -129,7 +140,10 @@ def main():
                 pending[bk] = None
             dem.set_result_target(bucket[bk].data_ptr() + slot * payload, payload)
             state["last"] = (bk, slot)
-        dem.demod_device_async(iq.data_ptr(), n)
+        if nch == 1:
+            dem.demod_device_async(iq.data_ptr(), n)
+        else:
+            dem.demod_device_async(iq.data_ptr(), n_ch, n_channels=nch, channel_stride=n_ch)
         state["launched"] = True
         if multi and slot == BUCKET - 1:
             flush(bk)
@@ -192,7 +206,7 @@ def main():
         ceil_ms = dem.time_read_ceiling(iq.data_ptr(), n * bps, 10)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc) and bps == 2 and n == 1 << 29:  # the PMC passes were taken on this exact workload
+        if os.path.exists(pmc) and bps == 2 and n == 1 << 29 and nch == 1 and dem.kernel == "tiles":  # the PMC passes were taken on this exact workload
             try:
                 traffic = json.load(open(pmc)).get("demod_tiles_hbm_bytes_per_launch")
             except Exception:
@@ -204,6 +218,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8" if bps == 2 else "u16", "data": "synthetic",
             "config": {"workload": f"2 MSPS {args.sample_type} IQ, {bps * n / 2**30:g} GiB synthetic buffer per GPU, fused magnitude+preamble/DF17 gate+PPM+CRC-24",
                        "samples_per_gpu": n, "bytes_per_gpu": bps * n, "frames_per_step": int(frames_per_step),
+                       "channels": nch,
                        "sharding": "single buffer" if world == 1 else f"time-sharded x{world}, 240-sample read halo, RCCL gather of frame lists",
                        "synth": {"seed": cfg.seed, "slot_len": cfg.slot_len, "noise_div": cfg.noise_div}},
             "msgs_per_s": round(frames_per_step * args.steps / dt, 1),
@@ -216,7 +231,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "read_ceiling_gbps": round(float(bps) * n / (ceil_ms * 1e-3) / 1e9, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline and bps == 2:
+        if world == 1 and not args.no_cpu_baseline and bps == 2 and nch == 1:
             sample = iq.cpu().numpy().reshape(-1, 2)  # the whole buffer: ~6-10 s on one host core
             out["cpu_baseline"] = cpu_baseline(sample)
         print(json.dumps(out), flush=True)
