@@ -147,18 +147,41 @@ __device__ __forceinline__ void mags8_i8(u32x4 v, uint32_t &lo, uint32_t &hi)
     hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[7]), 3, hi);
 }
 
-// floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): float estimate, then an exact integer
-// correction (the float path alone is off by one near perfect squares).
+// floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): n by one v_dot2_i32_i16, a float estimate biased
+// upward so that it can only be right or one too high, and one exact integer correction.
+// Error budget of sqrtf((float)n) at s = sqrt(n) <= 46341: conversion to float 2^-24 relative (2^-25 after
+// the root), v_sqrt_f32 one ulp (2^-23), the addition of the bias half an ulp of the sum (2^-9):
+// |e| <= 46341 * 1.5e-7 + 0.002 < 0.0089 < bias = 3/256.  So est is in (s, s + 0.021): floor(est) is
+// floor(s) or floor(s) + 1, and r * r > n tells which (r <= 46341: r * r < 2^32).
+__device__ __forceinline__ uint32_t mag_i16_root(uint32_t n)
+{
+    uint32_t r = (uint32_t)(__builtin_amdgcn_sqrtf((float)n) + 0.01171875f);
+    r -= (__umul24(r, r) > n) ? 1u : 0u; // r < 2^24: the 24-bit multiply is exact and full rate
+    return r;
+}
 __device__ __forceinline__ uint32_t mag_i16(uint32_t iq)
 {
-    int i = (int)(short)(iq & 0xFFFFu);
-    int q = (int)iq >> 16;
-    uint32_t n = (uint32_t)(i * i) + (uint32_t)(q * q);
-    uint32_t r = (uint32_t)__builtin_amdgcn_sqrtf((float)n);
-    r = r > 46341u ? 46341u : r;
-    r -= (r * r > n) ? 1u : 0u;            // estimate was one too high
-    r += ((r + 1u) * (r + 1u) <= n) ? 1u : 0u; // or one too low ((r+1)^2 <= 46342^2 < 2^32)
-    return r;
+    uint32_t n; // 2^31 for (-32768, -32768): the i32 result wraps to the right bits
+    // (VOP3P form with the inline constant 0 as accumulator: for the builtin hipcc picks v_dot2c, which needs
+    // a v_mov per call to preload it; gfx950 wants 3 wait states between a DOT and a VALU reading it)
+    asm("v_dot2_i32_i16 %0, %1, %1, 0\n\ts_nop 2" : "=v"(n) : "v"(iq));
+    return mag_i16_root(n);
+}
+// four samples (one 16-byte load): the dots issue back to back, one wait for all of them
+__device__ __forceinline__ void mags4_i16(u32x4 v, uint32_t m[4])
+{
+    uint32_t n0, n1, n2, n3;
+    asm("v_dot2_i32_i16 %0, %4, %4, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %5, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %6, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %7, 0\n\t"
+        "s_nop 2"
+        : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+        : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    m[0] = mag_i16_root(n0);
+    m[1] = mag_i16_root(n1);
+    m[2] = mag_i16_root(n2);
+    m[3] = mag_i16_root(n3);
 }
 
 // ---- probe: how does v_cvt_pk_u8_f32 round here? --------------------------------------------
@@ -605,9 +628,10 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 for (int it = 0; it < kIters; ++it) {
                     uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
                     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, s * 4, 0, 0);
-                    uint32_t m0 = mag_i16(v.x), m1 = mag_i16(v.y), m2 = mag_i16(v.z), m3 = mag_i16(v.w);
+                    uint32_t m[4];
+                    mags4_i16(v, m);
                     if (s < (uint32_t)TC::kMagT)
-                        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+                        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
                 }
             }
         }

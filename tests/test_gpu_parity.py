@@ -80,7 +80,13 @@ def test_magnitude_i16(dem16, oracle):
     ks = np.arange(1, 32768, 7)
     edge = np.concatenate([np.stack([ks, np.zeros_like(ks)], 1), np.stack([-ks, ks], 1),
                            np.array([[-32768, -32768], [32767, 32767], [0, 0], [-32768, 0], [181, 181]])])
-    iq = np.concatenate([iq, edge.astype(np.int16)])
+    # every perfect square and its neighbour the i16 range can carry: (k, 0) -> k^2, (k, 1) -> k^2 + 1, and the
+    # k^2 - 1 cases that are sums of two squares are met by the random draw (the biased float estimate in
+    # mag_i16 is exactly wrong there without its integer correction)
+    k = np.arange(0, 32768)
+    sq = np.concatenate([np.stack([k, np.zeros_like(k)], 1), np.stack([k, np.ones_like(k)], 1),
+                         np.stack([-k, k], 1), np.stack([k, -32768 * np.ones_like(k)], 1)])
+    iq = np.concatenate([iq, edge.astype(np.int16), sq.astype(np.int16)])
     assert (dem16.magnitudes(iq) == oracle.get_magnitude(iq)).all()
 
 
