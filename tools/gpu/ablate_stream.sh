@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box helper: ablation variants of the streaming kernel (no parity: results are wrong by design), then PMC passes.
+# GPU box helper: ablation variants of the streaming kernel (tools/build_variant.sh NAME -DADSB_ABL_NOLOOKUP=1 /
+# -DADSB_ABL_NOGATE=1; no parity: results are wrong by design), then PMC passes.
 set -o pipefail
 mkdir -p gpurun_out
 SKIP_TESTS=1 tools/gpu/compare_variants.sh default "$@" || exit 1
