@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""GPU box helper: randomized parity soak.  For `--seconds` of wall time: random buffer length, synthetic
+source parameters (frame density, noise level, error mix), sample type and i8 kernel; the HIP path's frame
+list must equal the CPU oracle's.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import air_rs_amd as A
+from tests.oracle_binding import Oracle
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+orc = Oracle()
+ctx = {}
+for kern in ("stream", "tiles"):
+    os.environ["ADSB_KERNEL"] = kern
+    ctx[(A.ADSB_SAMPLE_I8, kern)] = A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 19)
+ctx[(A.ADSB_SAMPLE_I16, "tiles")] = A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 22, max_out=1 << 19)
+t0 = time.time()
+runs = fails = frames_total = 0
+while time.time() - t0 < args.seconds:
+    st = A.ADSB_SAMPLE_I8 if rng.random() < 0.7 else A.ADSB_SAMPLE_I16
+    kern = "tiles" if st == A.ADSB_SAMPLE_I16 else ("stream" if rng.random() < 0.5 else "tiles")
+    n = int(rng.choice([rng.integers(240, 4000), rng.integers(4000, 200000), rng.integers(200000, 3000000)]))
+    cfg = A.synth_default(seed=int(rng.integers(1, 1 << 40)), slot_len=int(rng.choice([300, 600, 2000, 9000])))
+    cfg.noise_div = int(rng.choice([3, 8, 18, 60, 200]))
+    cfg.pct_flip_data = int(rng.integers(0, 30)); cfg.pct_flip_crc = int(rng.integers(0, 10)); cfg.pct_flip_two = int(rng.integers(0, 10))
+    cfg.frame_pct = int(rng.choice([0, 30, 100]))
+    if st == A.ADSB_SAMPLE_I16:
+        cfg.amp_shift = int(rng.integers(0, 8))
+    iq = A.synth_fill_host(cfg, st, int(rng.integers(0, 4)), int(rng.integers(0, 1 << 30)), n)
+    d = ctx[(st, kern)]
+    got, flags = d.demod(iq)
+    rc, want, found = orc.process_buffer(iq, max_out=d.max_out)
+    ok = rc == 0 and len(got) == len(want) and (got == want).all() and bool(flags & A.ADSB_FLAG_TRUNCATED) == (found > d.max_out)
+    runs += 1
+    frames_total += len(want)
+    if not ok:
+        fails += 1
+        print(f"MISMATCH st={st} kernel={kern} n={n} seed={cfg.seed} slot={cfg.slot_len} noise_div={cfg.noise_div} "
+              f"got {len(got)} want {len(want)}", flush=True)
+print(f"soak: {runs} buffers, {frames_total} frames compared, {fails} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if fails else 0)
