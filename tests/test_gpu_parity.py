@@ -385,3 +385,28 @@ def test_on_device_field_decode(gpu, oracle):
                 assert g[name] == k[name], name
         if "callsign" in k:
             assert g["callsign"].decode() == k["callsign"]
+
+
+@pytest.mark.parametrize("grid", [1, 3, 7])
+def test_stream_kernel_many_rounds_per_workgroup(gpu, oracle, kernel_kind, grid):
+    """The streaming kernel's persistent workgroups walk tiles b, b + G, b + 2G, ...: with the default grid
+    (one workgroup per CU) the buffers of this suite give every workgroup a single tile, so pin the grid to a
+    few workgroups and make each run many rounds (double-buffered magnitudes, parity-buffered lists, deferred
+    records) -- sparse rounds, dense rounds (constant stretch: a frame per offset) and the ragged last tile."""
+    if kernel_kind != "stream":
+        pytest.skip("streaming kernel only")
+    os.environ["ADSB_STREAM_GRID"] = str(grid)
+    try:
+        cfg = A.synth_default(seed=4000 + grid, slot_len=700)
+        n = 32768 * 21 + 12345
+        iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, n)
+        iq[32768 * 5 + 100:32768 * 5 + 2100] = 17        # constant stretch: > 64 survivors in tile 5 (dense round)
+        iq[32768 * 6 - 50:32768 * 6 + 400] = -3          # ... and one straddling a tile edge
+        with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=n, max_out=1 << 16) as d:
+            assert d.kernel == "stream"
+            fr = _check(d, oracle, iq)
+            assert len(fr) > 2500
+            fr2 = _check(d, oracle, iq[: 32768 * 9 + 241])   # same context, shorter buffer
+            assert 0 < len(fr2) < len(fr)
+    finally:
+        os.environ.pop("ADSB_STREAM_GRID", None)
