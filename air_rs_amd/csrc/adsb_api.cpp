@@ -98,10 +98,10 @@ struct adsb_ctx {
         if (e_ != hipSuccess) return (int)e_;      \
     } while (0)
 
-static uint32_t tiles_for(uint64_t n_samples, int sample_type)
+static uint32_t tiles_for(uint64_t n_samples, int sample_type, bool stream)
 {
     if (n_samples <= (uint64_t)kWindow) return 0;
-    const uint64_t n_off = n_samples - kWindow, tile = (uint64_t)adsbk::tile_offsets(sample_type);
+    const uint64_t n_off = n_samples - kWindow, tile = (uint64_t)adsbk::tile_offsets(sample_type, stream);
     return (uint32_t)((n_off + tile - 1) / tile);
 }
 
@@ -174,7 +174,15 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     if (!c) return ADSB_E_NOMEM;
     c->cfg = *cfg;
     c->bps = cfg->sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
-    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type) * cfg->max_channels;
+    // Two tile kernels exist for i8 input: one workgroup per tile (demod_tiles, also used for i16) and
+    // the streaming kernel (one persistent workgroup per CU, table-lookup magnitudes).  ADSB_KERNEL =
+    // "tiles" | "stream" picks one at adsb_create; the default is the faster one as measured on MI355X
+    // (DESIGN.md section 5).
+    const char *kern = getenv("ADSB_KERNEL");
+    const bool stream_default = ADSB_DEFAULT_STREAM != 0;
+    const bool want_stream = cfg->sample_type == ADSB_SAMPLE_I8 &&
+                 (kern ? strcmp(kern, "stream") == 0 : stream_default);
+    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type, want_stream) * cfg->max_channels;
     if (tiles == 0) tiles = 1;
     if (tiles * adsbk::kQuota + cfg->max_out + kTile > 0xFFFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
     c->n_tiles_max = (uint32_t)tiles;
@@ -238,14 +246,6 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         else if (probe[1] == want) c->mag_mode = 1;
         else c->mag_mode = 2;
         if (const char *force = getenv("ADSB_FORCE_MAG_MODE")) c->mag_mode = atoi(force) % 3;
-        // Two tile kernels exist for i8 input: one workgroup per tile (demod_tiles, also used for i16) and
-        // the streaming kernel (one persistent workgroup per CU, table-lookup magnitudes).  ADSB_KERNEL =
-        // "tiles" | "stream" picks one at adsb_create; the default is the faster one as measured on MI355X
-        // (DESIGN.md section 5).
-        const char *kern = getenv("ADSB_KERNEL");
-        const bool stream_default = ADSB_DEFAULT_STREAM != 0;
-        const bool want_stream = cfg->sample_type == ADSB_SAMPLE_I8 &&
-                                 (kern ? strcmp(kern, "stream") == 0 : stream_default);
         if (want_stream) {
             int n_cu = 0;
             if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) {
@@ -360,7 +360,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_channels = n_channels;
     c->last_samples = n_samples;
     c->last_stride = channel_stride;
-    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type);
+    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type, c->stream_grid != 0);
     c->last_tiles = c->last_tpc * n_channels;
     c->launched = true;
     c->fields_current = false;

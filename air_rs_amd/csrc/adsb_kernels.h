@@ -29,7 +29,12 @@ template <int ST> struct TileCfg {
     static constexpr int kTileT = 2 * kThreads * kRunT;
     static constexpr int kMagT = kTileT + kHalo;
 };
-constexpr int tile_offsets(int sample_type) { return sample_type == ADSB_SAMPLE_I8 ? kTile : 2 * kThreads * kRunI16; }
+// the streaming i8 kernel has its own tile length (three magnitude buffers + the table must fit the LDS)
+constexpr int kStreamTile = 2 * (64 * 7) * 32; // = kSTile in adsb_stream_kernel.h
+constexpr int tile_offsets(int sample_type, bool stream = false)
+{
+    return sample_type == ADSB_SAMPLE_I8 ? (stream ? kStreamTile : kTile) : 2 * kThreads * kRunI16;
+}
 constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
 constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path
 constexpr int kWindow = 240;    // 16 + 112*2  (reference src/adsb.rs:98)

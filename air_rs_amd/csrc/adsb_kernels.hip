@@ -285,10 +285,10 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
 // Lane l slices frame byte l (magnitudes off+16+16l .. +15, demod.rs:97-101).  The 24-byte record
 // {offset, bytes[14], status, fixed_bit} is written to `rec` (LDS); returns (on every lane) whether the
 // frame is valid (CRC matched, or one data bit repaired: crc.rs:49-65).
-template <int ST>
+template <int ST, bool NIBBLES = false>
 __device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *mag, const uint32_t *syn, unsigned char *rec,
                                                  const bool have, const uint32_t off, const uint64_t sample0,
-                                                 const uint32_t l, const uint32_t lane)
+                                                 const uint32_t l, const uint32_t lane, const uint32_t *nib = nullptr)
 {
     const uint32_t lb = l < 14 ? l : 13;
     uint32_t byte = 0;
@@ -317,7 +317,12 @@ __device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *
     // syndrome = XOR of table entries of the set bits, over the 14 bytes
     uint32_t s = 0;
     const uint32_t *sy = syn + 8 * lb;
-    {
+    if (NIBBLES) {
+        // nib[(2 lb + h) * 16 + v] = XOR of the syndromes of the bits set in nibble v (h = 0: bits 7..4):
+        // two LDS reads and one XOR instead of eight reads and sixteen VALU instructions
+        const uint32_t e = nib[(2 * lb) * 16 + (byte >> 4)] ^ nib[(2 * lb + 1) * 16 + (byte & 15u)];
+        s = l < 14 ? e : 0u;
+    } else {
         const int sb = (int)(l < 14 ? byte : 0u);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
@@ -541,12 +546,12 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
 }
 
 // The same descriptor as four dwords (for inline asm): base, base_hi (stride 0), num_records, flags.
-template <int BPS>
+template <int BPS, int MAG = kMag>
 __device__ __forceinline__ u32x4 tile_rsrc_words(const DemodArgs &p, const TilePos &t, bool live)
 {
     const uint64_t base = (uint64_t)(uintptr_t)((const char *)p.iq + ((uint64_t)t.ch * p.channel_stride + t.sample0) * BPS);
     const uint64_t remain = (p.n_samples - t.sample0) * BPS;
-    const uint32_t nrec = remain > (uint64_t)(kMag * BPS) ? (uint32_t)(kMag * BPS) : (uint32_t)remain;
+    const uint32_t nrec = remain > (uint64_t)(MAG * BPS) ? (uint32_t)(MAG * BPS) : (uint32_t)remain;
     u32x4 w;
     w.x = __builtin_amdgcn_readfirstlane((uint32_t)base);
     w.y = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xFFFFu);

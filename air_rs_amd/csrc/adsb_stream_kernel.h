@@ -5,19 +5,19 @@
 // slots, group counters), different mapping to the machine.  demod_tiles is VALU-issue-bound: 20 of
 // its ~54 issue cycles per 64 samples go into floor(sqrt(I^2+Q^2)) (v_dot4, v_add_f32, v_sqrt_f32,
 // v_cvt_pk_u8_f32), and a workgroup alternates between waiting for HBM and computing.  Here:
-//   * one persistent 512-thread workgroup per CU (it owns 134 KB of the CU's 160 KB LDS) walks tiles
-//     blockIdx.x, blockIdx.x + gridDim.x, ...;
+//   * one persistent 1024-thread workgroup per CU (it owns 158 KB of the CU's 160 KB LDS) walks tiles
+//     blockIdx.x, blockIdx.x + gridDim.x, ... (tiles of 28 672 offsets here);
 //   * the magnitude is a table lookup: an i8 IQ sample is 16 bits, so floor(sqrt(I^2+Q^2)) for every
 //     possible sample is a 64 KB byte table in LDS, indexed by the raw sample (index bits swizzled so
 //     that receiver noise spreads over all LDS banks).  Exact by construction (the table is built
 //     with integer arithmetic), no floating point anywhere on the path; the work moves from the VALU
 //     to the otherwise idle LDS pipe;
-//   * wave specialisation instead of co-resident workgroups: waves 4-7 ("lookup waves") stream the
-//     raw IQ of tile i+1 from HBM (each consumed 16-byte register is immediately re-loaded with tile
-//     i+2's data, so ~68 KB per CU are always in flight), look the magnitudes up and write them to the
-//     second of two LDS magnitude buffers, while waves 0-3 ("gate waves") run the preamble/DF17 gate
-//     and the PPM/CRC decode of tile i from the first buffer.  One gate wave and one lookup wave share
-//     each SIMD: the gate wave uses its VALU, the lookup wave the LDS and memory pipes.
+//   * wave specialisation instead of co-resident workgroups: three roles work on three consecutive
+//     tiles at the same time, through three LDS magnitude buffers, with ONE workgroup barrier per round:
+//     5 "lookup waves" stream tile i+2 from HBM (each consumed 16-byte register quad is immediately
+//     re-loaded, in place, with the next tile's data: ~58 KB per CU always in flight) and convert tile
+//     i+1; 7 "gate waves" run the preamble/DF17 gate of tile i; 4 "decode waves" slice, CRC-check and
+//     repair tile i-1's survivors into frame records staged in LDS and write tile i-2's out.
 #pragma once
 
 // ablation switches for measurements (tools/gpu): results are wrong when set
@@ -56,34 +56,31 @@
 #define STAMP(k) do { } while (0)
 #endif
 
-// Eight gate waves (two per SIMD: one wave alone issues an instruction only every ~16 cycles, the
-// VALU -> SGPR -> s_cbranch chain of every gate step being fully exposed) + four lookup waves.
-constexpr int kSGateThreads = 512;           // 8 gate waves: 2 runs of kSRun offsets per lane
-constexpr int kSRun = kTile / (2 * kSGateThreads); // 32
-#ifndef ADSB_STREAM_D_AT
-#define ADSB_STREAM_D_AT 14 // gate step (of kSRun = 32) before which the gate waves take barrier D
-#endif
-#ifndef ADSB_STREAM_LOOKUP_WAVES
-#define ADSB_STREAM_LOOKUP_WAVES 8
-#endif
-constexpr int kSLookupThreads = 64 * ADSB_STREAM_LOOKUP_WAVES; // lookup waves: sweeps of 16 B (8 samples) per lane
+// Three roles in one 1024-thread workgroup, one barrier per round:
+//   7 gate waves    preamble/DF17 gate of tile i (2 runs of 32 offsets per lane -> 28 672-offset tiles)
+//   5 lookup waves  stream tile i+2 from HBM, convert tile i+1 into a magnitude buffer by table lookup
+//   4 decode waves  PPM slice + CRC-24 + repair of tile i-1's survivors (16 groups: one pass for the usual
+//                   ~15 per tile), frames staged in LDS
+// Three magnitude buffers (28 928 B each) + the 64 KB table fill the CU's LDS; that is what sets the
+// tile length.
+constexpr int kSGateWaves = 7, kSLookupWaves = 5, kSDecodeWaves = 4;
+constexpr int kSGateThreads = 64 * kSGateWaves;
+constexpr int kSRun = 32;
+constexpr int kSTile = 2 * kSGateThreads * kSRun; // 28 672 offsets per tile
+constexpr int kSMag = kSTile + kHalo;             // 28 928 magnitudes per buffer
+static_assert(kSTile == kStreamTile, "the host's tile length for this kernel");
+constexpr int kSLookupThreads = 64 * kSLookupWaves;
 constexpr int kSSweep = kSLookupThreads * 8;                  // samples per sweep of all lookup waves
-constexpr int kSFull = kTile / kSSweep;                       // full sweeps per tile ...
-constexpr int kSIters = kSFull + 1;                           // ... + one sweep for the kHalo extra samples
-static_assert(kTile % kSSweep == 0 && kHalo <= kSSweep, "sweep layout");
+constexpr int kSIters = (kSMag + kSSweep - 1) / kSSweep;      // 12 sweeps (the last one partial)
 #define ADSB_STR2(x) #x
 #define ADSB_STR(x) ADSB_STR2(x)
 // when a sweep's quad is consumed, the kSIters - 1 loads issued after its own may still be in flight
-#if ADSB_STREAM_LOOKUP_WAVES == 8
-#define ADSB_STREAM_VMCNT 8
-#elif ADSB_STREAM_LOOKUP_WAVES == 4
-#define ADSB_STREAM_VMCNT 16
-#else
-#error "ADSB_STREAM_LOOKUP_WAVES must be 4 or 8"
-#endif
+#define ADSB_STREAM_VMCNT 11
 static_assert(ADSB_STREAM_VMCNT == kSIters - 1, "wait count matches the number of sweeps");
-constexpr int kSThreads = kSGateThreads + kSLookupThreads;
-constexpr int kSGroups = kSGateThreads / 16; // 16-lane decode groups
+constexpr int kSDecodeThreads = 64 * kSDecodeWaves;
+constexpr int kSThreads = kSGateThreads + kSLookupThreads + kSDecodeThreads;
+static_assert(kSThreads == 1024, "16 waves");
+constexpr int kSDenseGroups = kSGateThreads / 16; // 16-lane groups of the gate waves (dense interlude)
 constexpr int kLutBytes = 65536;
 
 // Table index of a raw sample r = (Q << 8) | I (little-endian i8 pair).  The LDS bank of a byte
@@ -114,27 +111,12 @@ hipError_t launch_build_lut(hipStream_t s, uint8_t *lut_dev)
     return hipGetLastError();
 }
 
+#ifndef ADSB_STREAM_RECORD_WAVE
+#define ADSB_STREAM_RECORD_WAVE 3 // which decode wave writes the per-tile records (the last one: its groups are the least often busy)
+#endif
 #ifndef ADSB_STREAM_GATE_GROUP
 #define ADSB_STREAM_GATE_GROUP 1 // gate steps per wave-uniform test (see gate_phase; 1 measured fastest)
 #endif
-
-struct SLds {
-    static constexpr int kOffLut = 0;
-    static constexpr int kOffMag0 = kLutBytes;
-    static constexpr int kOffMag1 = kOffMag0 + kMag;
-    static constexpr int kOffCand = kOffMag1 + kMag;            // survivor bitmap, 1024 words
-    static constexpr int kOffList = kOffCand + 2 * kThreads * 8; // 2 (round parity) x kListCap x u16
-    static constexpr int kOffSyn = kOffList + 2 * kListCap * 2;
-    static constexpr int kOffStage = kOffSyn + 112 * 4;         // 2 (round parity) x kSparseCap x 24 B frame records
-    static constexpr int kOffRes = kOffStage + 2 * kSparseCap * 24; // dense path: per-group record staging
-    static constexpr int kOffMisc = kOffRes + kSGroups * 24;
-    static constexpr int kTotal = kOffMisc + 64;
-    // misc words: [0..3] dense-path partial sums, [8 + parity] valid frames of the round,
-    // [10] pool allocation of an over-quota tile (dense path), [12 + parity] gate survivors of the round
-    static constexpr int kValid = 8, kAlloc = 10, kCount = 12;
-};
-static_assert(SLds::kTotal <= 160 * 1024, "LDS budget");
-static_assert(kMag % 16 == 0 && SLds::kOffStage % 8 == 0, "alignment of the LDS regions");
 
 // Table indices of the 8 raw samples of one 16-byte load (both samples of a dword share the swizzle) ...
 __device__ __forceinline__ void lookup_indices(u32x4 v, uint32_t x[4])
@@ -201,38 +183,64 @@ __device__ __forceinline__ void lookup_indices8_lean(u32x4 v, uint32_t idx[8])
     }
 }
 
-// Barrier schedule shared by the two roles (every wave executes the same sequence of s_barrier):
-//   P1  table in LDS                      P2  tile 0 converted
-//   per round i = 0 .. n_my:   D(i)  inside the gate of tile i (the last round has no gate: bare D)
-//                              B1(i) after gate(i) and conversion(i+1)           [i < n_my]
-//                              dense rounds only (more than kSparseCap survivors): BD, BA, {BC1, BC2}*, X
-// Round i in the normal (sparse) case:
-//   gate waves    gate(i) first part | D(i) | gate(i) rest, then thread/wave 0 writes tile i-1's record and
-//                 its staged frames to global memory | B1(i)
-//   lookup waves  decode(i-1): survivors of tile i-1 -> frame records staged in LDS | D(i) | conversion of
-//                 tile i+1 into the buffer tile i-1 occupied, re-loading the raw registers with tile i+2 | B1(i)
-// The survivor list, the counters and the frame staging are double-buffered by round parity.
+// Round i of a workgroup (tiles t_k = tile_first + blockIdx.x + k * gridDim.x), all three at the same time:
+//   gate waves     gate(i):    tile i's magnitudes (buffer i % 3) -> survivors in list[i % 2], count[i % 3]
+//   lookup waves   pass i+2:   raw registers (tile i+1) -> magnitudes in buffer (i+1) % 3, registers re-loaded
+//                              with tile i+2
+//   decode waves   decode(i-1): survivors of tile i-1 (buffer (i-1) % 3, list[(i-1) % 2]) -> frame records in
+//                              stage[(i-1) % 2], valid[(i-1) % 3]; then one of them writes the record of tile i-2
+//                              (Seg, group counters, its staged frames -> global frame slots)
+//   R(i)           ONE workgroup barrier ends the round.
+// If gate(i) found more than kSparseCap survivors (pathological inputs) a "dense interlude"
+// follows R(i): the gate waves decode tile i in place, straight to global memory, with the ordered
+// bitmap compaction of demod_tiles; the other waves only take part in its barriers (every wave derives
+// their number from the same LDS words).  Barriers before the first round: P1 (table in LDS), P2 (tile 0
+// converted).  Rounds run i = 0 .. n_my + 1 so that the last tiles drain.
+struct SLds {
+    static constexpr int kOffLut = 0;
+    static constexpr int kOffMag = kLutBytes;                      // 3 buffers of kSMag bytes
+    static constexpr int kOffCand = kOffMag + 3 * kSMag;           // survivor bitmap of the tile being gated: kSTile / 32 words
+    static constexpr int kOffList = kOffCand + kSTile / 8;         // 2 (round parity) x kListCap x u16
+    static constexpr int kOffSyn = kOffList + 2 * kListCap * 2;
+    static constexpr int kOffStage = kOffSyn + 112 * 4;            // 2 (round parity) x kSparseCap x 24 B frame records
+    static constexpr int kOffRes = kOffStage + 2 * kSparseCap * 24; // dense interlude: per-group record staging
+    static constexpr int kOffNib = kOffRes + kSDenseGroups * 24;   // 28 nibble positions x 16 syndrome sums (u32)
+    static constexpr int kOffMisc = kOffNib + 28 * 16 * 4;
+    static constexpr int kTotal = kOffMisc + 64;
+    // misc words: [0..3] dense partial sums, [4] dense pool allocation, [5 + i%3] slot base of a dense tile i,
+    // [8 + i%3] valid frames of tile i, [12 + i%3] gate survivors of tile i
+    static constexpr int kAlloc = 4, kDenseBase = 5, kValid = 8, kCount = 12;
+    __device__ static constexpr int mag_off(uint32_t k) { return kOffMag + (int)k * kSMag; }
+};
+static_assert(SLds::kTotal <= 160 * 1024, "LDS budget");
+static_assert(kSMag % 16 == 0 && SLds::kOffStage % 8 == 0 && SLds::kOffCand % 16 == 0, "alignment of the LDS regions");
 
-// ---- role: lookup waves (the last ADSB_STREAM_LOOKUP_WAVES) ----------------------------------------------
+// barriers of a dense interlude for the waves that only take part in them
+__device__ __forceinline__ void dense_interlude_mirror(const uint32_t *misc)
+{
+    __syncthreads(); // BD
+    const uint32_t total = misc[0] + misc[1] + misc[2] + misc[3];
+    __syncthreads(); // BA
+    for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+        __syncthreads(); // BC1
+        __syncthreads(); // BC2
+    }
+    __syncthreads(); // BX
+}
+
+// ---- role: lookup waves -----------------------------------------------------------------------------------
 __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned char *smem, const uint32_t tg,
                                                    const uint32_t tile0, const uint32_t G, const uint32_t n_my)
 {
     typedef SLds L;
     const unsigned char *lut = smem + L::kOffLut;
-    const uint16_t *lists = reinterpret_cast<const uint16_t *>(smem + L::kOffList);
-    const uint32_t *syn = reinterpret_cast<const uint32_t *>(smem + L::kOffSyn);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
-    const uint32_t lane = tg & 63;
-    const uint32_t lwave = __builtin_amdgcn_readfirstlane(tg >> 6);
-    const uint32_t wave_s0 = lwave * 64 * 8; // first sample of this wave's sweep
-    const uint32_t g = tg >> 4, l = tg & 15;  // 16-lane decode groups
+    const uint32_t *misc = reinterpret_cast<const uint32_t *>(smem + L::kOffMisc);
 
-    // Conversion pass r converts tile r-1 (if 1 <= r <= n_my) from the raw registers into magnitude buffer
-    // (r-1)&1 and re-loads every consumed register, in place, with the same piece of tile r (if r < n_my;
-    // otherwise through an empty descriptor: zeros, no traffic).  Pass 0 and the passes after n_my convert
-    // zeros into a buffer nobody reads: one uniform, branch-free body.  All loads are issued
-    // unconditionally: lanes past the tile's samples -- most of the last sweep, which only covers the
-    // 256-sample halo -- are clipped by the descriptor and cost no traffic.
+    // Pass r converts tile r-1 (if 1 <= r <= n_my) from the raw registers into magnitude buffer (r-1) % 3 and
+    // re-loads every consumed register, in place, with the same piece of tile r (if r < n_my; otherwise
+    // through an empty descriptor: zeros, no traffic).  Pass 0 and the passes after n_my convert zeros into a
+    // buffer nobody reads: one uniform, branch-free body.  All loads are issued unconditionally: lanes past
+    // the tile's samples are clipped by the descriptor and cost no traffic.
     //
     // The loads and their waits are inline asm.  With the builtin, every formulation tried made hipcc
     // either drain (s_waitcnt vmcnt(0)) or rotate the register quads through one v_mov each per pass,
@@ -240,60 +248,24 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
     // will be consumed from.  Tied operands ("+v") pin each quad; the wait is explicit: when sweep `it`
     // is consumed, the kSIters - 1 loads issued after its own (the rest of the previous pass, the start of
     // this one) may still be in flight -> s_waitcnt vmcnt(kSIters - 1).  These waves issue no other vector
-    // memory instruction (decoded frames are staged in LDS and stored by a gate wave), so the count is
-    // exact.  (hipcc must not copy a quad between its load and its wait: checked in the ISA.)
+    // memory instruction, so the count is exact.  (hipcc must not copy a quad between its load and its
+    // wait: checked in the ISA.)
     u32x4 raw[kSIters];
 #pragma unroll
     for (int it = 0; it < kSIters; ++it) raw[it] = u32x4{0u, 0u, 0u, 0u};
 
     STAMP_DECL;
     STAMP_START();
-    bool prev_dense = false; // round r-3 took the dense path (its frames are already in global memory)
-    for (uint32_t r = 0; r <= n_my + 2; ++r) {
-        // ---- decode of tile r-3 (round i-1 for i = r-2), then D(i) ----------------------------------------
-        if (r >= 2) {
-            if (r >= 3 && !prev_dense) {
-                const uint32_t jp = (r - 3) & 1u;
-                const uint32_t total = misc[L::kCount + jp];
-                if (total) {
-                    const uint16_t *list = lists + jp * kListCap;
-                    const unsigned char *mag = smem + (jp ? L::kOffMag1 : L::kOffMag0);
-                    unsigned char *stage = smem + L::kOffStage + jp * (kSparseCap * 24);
-                    const TilePos tpd = tile_pos(p, tile0 + (r - 3) * G);
-                    // The list is unordered; a candidate's slot is its rank: the number of listed offsets
-                    // below its own.  total <= kSparseCap = 64 = 16 lanes x 4.
-                    for (uint32_t c0 = 0; c0 < total; c0 += kSLookupThreads / 16) {
-                        if (c0 + 4 * lwave >= total) break; // none of this wave's four groups has a candidate
-                        const uint32_t ci = c0 + g;
-                        const bool have = ci < total; // uniform within the 16-lane group
-                        const uint32_t off = have ? list[ci] : 0u;
-                        uint32_t below = 0;
-#pragma unroll
-                        for (int k = 0; k < kSparseCap / 16; ++k) {
-                            const uint32_t j = l + 16 * k;
-                            const uint32_t e = j < total ? (uint32_t)list[j] : 0xFFFFFFFFu;
-                            below += e < off ? 1u : 0u;
-                        }
-                        below = row16_sum(below);
-                        const bool valid = decode_candidate<ADSB_SAMPLE_I8>(mag, syn, stage + (have ? below : 0u) * 24, have, off, tpd.sample0, l, lane);
-                        if (valid && l == 0) atomicAdd(&misc[L::kValid + jp], 1u);
-                    }
-                }
-            }
-            STAMP(3); // decode
-            __syncthreads(); // D(i)
-            STAMP(1);
-        }
-        // ---- conversion pass r ---------------------------------------------------------------------------
-        unsigned char *dst = smem + ((r & 1u) ? L::kOffMag0 : L::kOffMag1); // buffer (r-1)&1
+    for (uint32_t r = 0; r <= n_my + 3; ++r) {
+        unsigned char *dst = smem + L::mag_off((r + 2) % 3); // buffer (r-1) % 3
         const bool more = r < n_my;
-        const TilePos tpn = tile_pos(p, more ? tile0 + r * G : tile0);
-        const u32x4 rn = tile_rsrc_words<2>(p, tpn, more);
+        const TilePos tpn = tile_pos<kSTile>(p, more ? tile0 + r * G : tile0);
+        const u32x4 rn = tile_rsrc_words<2, kSMag>(p, tpn, more);
         // Software pipeline: the byte reads of sweep `it` are issued before the magnitudes of sweep
         // `it - 1` are packed and stored, so a wave always has 8-16 table reads in flight.
         uint32_t mprev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int it = 0; it < kSIters - 1; ++it) {
+        for (int it = 0; it < kSIters; ++it) {
             uint32_t idx[8], m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             asm volatile("s_waitcnt vmcnt(" ADSB_STR(ADSB_STREAM_VMCNT) ")" : "+v"(raw[it]));
             lookup_indices8_lean(raw[it], idx);
@@ -307,41 +279,14 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
             // with them the waits, to the top of the pass)
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!ADSB_ABL_NOLOOKUP)
-            *reinterpret_cast<uint2 *>(dst + (uint32_t)(kSIters - 2) * (kSLookupThreads * 8) + tg * 8) = lookup_pack(mprev);
-        {
-            // the last sweep only covers the 256-sample halo: 32 lanes of the first lookup wave
-            constexpr int it = kSIters - 1;
-            uint32_t idx[8];
-            asm volatile("s_waitcnt vmcnt(" ADSB_STR(ADSB_STREAM_VMCNT) ")" : "+v"(raw[it]));
-            lookup_indices8(raw[it], idx);
-            reload_in_place(raw[it], idx, (uint32_t)it * (kSLookupThreads * 16) + tg * 16, rn);
-            if (wave_s0 == 0 && !ADSB_ABL_NOLOOKUP) { // scalar branch
-                const uint32_t s = (uint32_t)it * (kSLookupThreads * 8) + tg * 8;
-                uint32_t m[8];
-                lookup_reads8(lut, idx, m);
-                if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(dst + s) = lookup_pack(m);
-            }
+        if (!ADSB_ABL_NOLOOKUP) { // the last sweep is partial: only lanes inside the buffer store
+            const uint32_t s = (uint32_t)(kSIters - 1) * (kSLookupThreads * 8) + tg * 8;
+            if (s < (uint32_t)kSMag) *reinterpret_cast<uint2 *>(dst + s) = lookup_pack(mprev);
         }
         STAMP(0); // conversion pass
-        if (r == n_my + 2) break; // round n_my has no B1
-        __syncthreads(); // P1 (r = 0), P2 (r = 1), B1(r - 2)
-        STAMP(2); // wait for the gate waves
-        if (r < 2) continue;
-        // mirror of the gate role's barriers for round i = r - 2
-        const uint32_t par = r & 1u;
-        uint32_t total = misc[L::kCount + par];
-        prev_dense = total > (uint32_t)kSparseCap;
-        if (prev_dense) {
-            __syncthreads(); // BD
-            total = misc[0] + misc[1] + misc[2] + misc[3];
-            __syncthreads(); // BA
-            for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
-                __syncthreads(); // BC1
-                __syncthreads(); // BC2
-            }
-            __syncthreads(); // X
-        }
+        __syncthreads(); // P1 (r = 0), P2 (r = 1), R(r - 2)
+        STAMP(1); // wait for the other roles
+        if (r >= 2 && r - 2 < n_my && misc[L::kCount + (r - 2) % 3] > (uint32_t)kSparseCap) dense_interlude_mirror(misc);
     }
     // nothing may be in flight into registers when the wave ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -351,7 +296,111 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
 #endif
 }
 
-// ---- role: gate waves (the first eight) --------------------------------------------------------------------
+// ---- role: decode waves -----------------------------------------------------------------------------------
+__device__ __forceinline__ void stream_decode_role(const DemodArgs &p, unsigned char *smem, const uint32_t tg,
+                                                   const uint32_t tile0, const uint32_t G, const uint32_t n_my)
+{
+    typedef SLds L;
+    const uint16_t *lists = reinterpret_cast<const uint16_t *>(smem + L::kOffList);
+    const uint32_t *syn = reinterpret_cast<const uint32_t *>(smem + L::kOffSyn);
+    const uint32_t *nib = reinterpret_cast<const uint32_t *>(smem + L::kOffNib);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
+    const uint32_t lane = tg & 63;
+    const uint32_t dwave = __builtin_amdgcn_readfirstlane(tg >> 6);
+    const uint32_t g = tg >> 4, l = tg & 15; // 16-lane groups: one candidate each, one lane per frame byte
+
+    __syncthreads(); // P1
+    __syncthreads(); // P2
+    STAMP_DECL;
+    STAMP_START();
+
+    // Record of tile j (local index), written by one decode wave two rounds after the tile's gate: the
+    // frames the decode waves staged in LDS go to the tile's slots (its own kQuota slots, or a block of the
+    // shared pool), then Seg + group counters, and the tile's counters are re-armed for tile j + 3.  A dense
+    // tile's frames were stored by its interlude, which also left its slot base in LDS.
+    auto record = [&](const uint32_t j) {
+        if (dwave != ADSB_STREAM_RECORD_WAVE) return;
+        const uint32_t tile = tile0 + j * G, k3 = j % 3;
+        const uint32_t total = misc[L::kCount + k3];
+        const bool dense = total > (uint32_t)kSparseCap;
+        uint32_t base = tile * kQuota;
+        if (dense) {
+            base = misc[L::kDenseBase + k3];
+        } else {
+            if (total > kQuota) {
+                uint32_t b = 0;
+                if (lane == 0) {
+                    const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+                    b = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
+                }
+                base = __builtin_amdgcn_readfirstlane(b);
+            }
+            if (base != kNoBase) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(smem + L::kOffStage + (j & 1u) * (kSparseCap * 24));
+                uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base);
+                for (uint32_t k = lane; k < total * 6; k += 64) dst[k] = src[k];
+            }
+        }
+        if (lane == 0) {
+            Seg e;
+            e.base = base;
+            e.cand = total;
+            e.valid = misc[L::kValid + k3];
+            e.pad = 0;
+            p.seg[tile] = e;
+            if (e.valid && p.count_groups) {
+                atomicAdd(&p.grp1[tile >> kGrpShift], e.valid);
+                atomicAdd(&p.grp2[(tile >> (2 * kGrpShift)) * kGrp2Shards + ((tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
+            }
+            misc[L::kValid + k3] = 0;
+            misc[L::kCount + k3] = 0;
+        }
+    };
+
+    for (uint32_t i = 0; i <= n_my + 1; ++i) {
+        if (i >= 1 && i <= n_my) {
+            const uint32_t j = i - 1; // tile index (local) being decoded
+            const uint32_t total = misc[L::kCount + j % 3];
+            if (total && total <= (uint32_t)kSparseCap) { // (a dense tile was decoded in its interlude)
+                const uint16_t *list = lists + (j & 1u) * kListCap;
+                const unsigned char *mag = smem + L::mag_off(j % 3);
+                unsigned char *stage = smem + L::kOffStage + (j & 1u) * (kSparseCap * 24);
+                const TilePos tpd = tile_pos<kSTile>(p, tile0 + j * G);
+                // The list is unordered; a candidate's slot is its rank: the number of listed offsets below
+                // its own.  total <= kSparseCap = 64 = 16 lanes x 4.
+                for (uint32_t c0 = 0; c0 < total; c0 += kSDecodeThreads / 16) {
+                    if (c0 + 4 * dwave >= total) break; // none of this wave's four groups has a candidate
+                    const uint32_t ci = c0 + g;
+                    const bool have = ci < total; // uniform within the 16-lane group
+                    const uint32_t off = have ? list[ci] : 0u;
+                    uint32_t below = 0;
+#pragma unroll
+                    for (int k = 0; k < kSparseCap / 16; ++k) {
+                        const uint32_t q = l + 16 * k;
+                        const uint32_t e = q < total ? (uint32_t)list[q] : 0xFFFFFFFFu;
+                        below += e < off ? 1u : 0u;
+                    }
+                    below = row16_sum(below);
+                    const bool valid = decode_candidate<ADSB_SAMPLE_I8, true>(mag, syn, stage + (have ? below : 0u) * 24, have, off,
+                                                                              tpd.sample0, l, lane, nib);
+                    if (valid && l == 0) atomicAdd(&misc[L::kValid + j % 3], 1u);
+                }
+            }
+        }
+        STAMP(0); // decode
+        if (i >= 2) record(i - 2);
+        STAMP(2); // record
+        __syncthreads(); // R(i)
+        STAMP(1);
+        if (i < n_my && misc[L::kCount + i % 3] > (uint32_t)kSparseCap) dense_interlude_mirror(misc);
+    }
+#if ADSB_STAMPS
+    if (blockIdx.x == 0 && tg == 0 && p.stamps)
+        for (int k = 0; k < 3; ++k) p.stamps[12 + k] = st_acc[k];
+#endif
+}
+
+// ---- role: gate waves -------------------------------------------------------------------------------------
 __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned char *smem, const uint32_t tid,
                                                  const uint32_t tile0, const uint32_t G, const uint32_t n_my)
 {
@@ -364,89 +413,36 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
     const uint32_t lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t g = tid >> 4, l = tid & 15; // kSGroups groups of 16 lanes (dense path decode)
+    const uint32_t g = tid >> 4, l = tid & 15; // dense interlude: kSDenseGroups groups of 16 lanes
 
     __syncthreads(); // P1
     __syncthreads(); // P2: tile 0's magnitudes are in buffer 0
     STAMP_DECL;
     STAMP_START();
 
-    // Record of a finished sparse round, written by wave 0 one round later (after the next gate, where
-    // the gate waves wait for the lookup waves anyway): the frames the lookup waves staged in LDS go to
-    // the tile's slots, then Seg + group counters; the round's counters are re-armed for the round after
-    // next (same parity; D and B1 of the round in between order that).
-    bool rec_pending = false, rec_dense = false;
-    uint32_t rec_tile = 0, rec_base = 0, rec_total = 0, rec_par = 0;
-    auto record = [&]() {
-        if (wave == 0 && rec_pending) {
-            if (!rec_dense && rec_base != kNoBase) {
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(smem + L::kOffStage + rec_par * (kSparseCap * 24));
-                uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)rec_base);
-                for (uint32_t k = lane; k < rec_total * 6; k += 64) dst[k] = src[k];
-            }
-            if (lane == 0) {
-                Seg e;
-                e.base = rec_base;
-                e.cand = rec_total;
-                e.valid = misc[L::kValid + rec_par];
-                e.pad = 0;
-                p.seg[rec_tile] = e;
-                if (e.valid && p.count_groups) {
-                    atomicAdd(&p.grp1[rec_tile >> kGrpShift], e.valid);
-                    atomicAdd(&p.grp2[(rec_tile >> (2 * kGrpShift)) * kGrp2Shards + ((rec_tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
-                }
-                misc[L::kValid + rec_par] = 0;
-                misc[L::kCount + rec_par] = 0;
-            }
-        }
-        rec_pending = false;
-    };
-
-    for (uint32_t i = 0; i <= n_my; ++i) {
+    for (uint32_t i = 0; i <= n_my + 1; ++i) {
         const bool live = i < n_my;
         const uint32_t tile = tile0 + (live ? i : 0u) * G;
-        const TilePos tp = tile_pos(p, tile);
-        const uint64_t sample0 = tp.sample0;
-        const unsigned char *mag = smem + ((i & 1u) ? L::kOffMag1 : L::kOffMag0);
-        const uint32_t par = i & 1u;
-        uint16_t *list = lists + par * kListCap;
+        const TilePos tp = tile_pos<kSTile>(p, tile);
+        const unsigned char *mag = smem + L::mag_off(i % 3);
+        uint16_t *list = lists + (i & 1u) * kListCap;
 
-        if (live && !ADSB_ABL_NOGATE) {
-            gate_phase<ST, ADSB_STREAM_GATE_GROUP, kSRun, kSGateThreads, ADSB_STREAM_D_AT>(
-                mag, cand, list, &misc[L::kCount + par], tid, tp.n_valid, [] { __syncthreads(); /* D(i) */ });
-        } else {
-            __syncthreads(); // D(i)
-        }
+        if (live && !ADSB_ABL_NOGATE)
+            gate_phase<ST, ADSB_STREAM_GATE_GROUP, kSRun, kSGateThreads>(mag, cand, list, &misc[L::kCount + i % 3], tid, tp.n_valid);
         STAMP(0); // gate
-        record(); // of round i - 1
-        STAMP(6);
-        if (!live) break;
-        __syncthreads(); // B1(i): survivors listed; the lookup waves have filled the other buffer
-        STAMP(1); // wait for the lookup waves
+        __syncthreads(); // R(i)
+        STAMP(1);
+        if (!live) continue;
 
-        uint32_t total = misc[L::kCount + par];
-        const bool dense = total > (uint32_t)kSparseCap;
-        uint32_t base_slot = tile * kQuota;
-        if (!dense) {
-            // Normal case: nothing more to do here; the lookup waves decode the survivors next round.
-            // Over-quota tiles draw their slots from the shared pool (thread 0; the result is only needed
-            // by wave 0's record()).
-            if (total > kQuota && wave == 0) {
-                uint32_t b = 0;
-                if (lane == 0) {
-                    const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
-                    b = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
-                }
-                base_slot = __builtin_amdgcn_readfirstlane(b);
-            }
-        } else {
-            // Dense fallback (pathological inputs): ordered compaction of the bitmap (1024
-            // words; offset 32 w + b is bit b of word w) by prefix sums over the first four gate waves, four
-            // words per lane; decode in place by the gate waves, straight to global memory.
+        uint32_t total = misc[L::kCount + i % 3];
+        if (total > (uint32_t)kSparseCap) {
+            // Dense interlude: ordered compaction of the bitmap (kSTile / 32 words; offset 32 w + b is bit b of
+            // word w) by prefix sums over the first four gate waves, four words per lane; decode in place by
+            // the gate waves, straight to global memory.
             u32x4 cw = {0, 0, 0, 0};
             uint32_t cnt = 0, incl = 0;
             if (wave < 4) {
-                cw = reinterpret_cast<const u32x4 *>(cand)[tid]; // bitmap words 4*tid .. 4*tid+3
+                if (4 * tid < (uint32_t)(kSTile / 32)) cw = reinterpret_cast<const u32x4 *>(cand)[tid];
                 cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) +
                       __builtin_popcount(cw.w);
                 incl = cnt;
@@ -472,7 +468,8 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
                 misc[L::kAlloc] = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
             }
             __syncthreads(); // BA
-            base_slot = misc[L::kAlloc];
+            const uint32_t base_slot = misc[L::kAlloc];
+            if (tid == 0) misc[L::kDenseBase + i % 3] = base_slot;
             for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
                 if (cnt) {
                     uint32_t idx = my_first;
@@ -491,13 +488,13 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
                 }
                 __syncthreads(); // BC1
                 const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
-                for (uint32_t r = 0; r < ncl; r += kSGroups) {
+                for (uint32_t r = 0; r < ncl; r += kSDenseGroups) {
                     if (r + 4 * wave >= ncl) break;
                     const uint32_t ci = r + g;
                     const bool have = ci < ncl;
                     unsigned char *rec = res + g * 24;
-                    const bool valid = decode_candidate<ADSB_SAMPLE_I8>(mag, syn, rec, have, have ? list[ci] : 0u, sample0, l, lane);
-                    if (valid && l == 0) atomicAdd(&misc[L::kValid + par], 1u);
+                    const bool valid = decode_candidate<ADSB_SAMPLE_I8>(mag, syn, rec, have, have ? list[ci] : 0u, tp.sample0, l, lane);
+                    if (valid && l == 0) atomicAdd(&misc[L::kValid + i % 3], 1u);
                     if (have && base_slot != kNoBase && l < 6) {
                         uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);
                         dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
@@ -505,14 +502,10 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
                 }
                 __syncthreads(); // BC2
             }
-            __syncthreads(); // X: in-place decode done before the lookup waves overwrite the buffer
+            // the record must see the compacted total, not the (saturating) survivor count of the sparse path
+            if (tid == 0) misc[L::kCount + i % 3] = total;
+            __syncthreads(); // BX: in-place decode done before the buffer, the bitmap and the list are reused
         }
-        rec_pending = true;
-        rec_dense = dense;
-        rec_tile = tile;
-        rec_base = base_slot;
-        rec_total = total;
-        rec_par = par;
     }
 #if ADSB_STAMPS
     if (blockIdx.x == 0 && tid == 0 && p.stamps) {
@@ -537,6 +530,11 @@ __global__ __launch_bounds__(kSThreads, 1) void demod_stream_i8(DemodArgs p)
         for (uint32_t k = tid; k < (uint32_t)(kLutBytes / 16); k += kSThreads)
             reinterpret_cast<u32x4 *>(lut)[k] = reinterpret_cast<const u32x4 *>(p.lut)[k];
         if (tid < 112) syn[tid] = kSyn.v[tid];
+        if (tid < 28 * 16) { // nibble sums of the syndrome table (decode_candidate<.., true>)
+            uint32_t e = 0;
+            for (int b = 0; b < 4; ++b) e ^= ((tid >> (3 - b)) & 1u) ? kSyn.v[4 * (tid >> 4) + b] : 0u;
+            reinterpret_cast<uint32_t *>(smem + L::kOffNib)[tid] = e;
+        }
         if (tid < 16) misc[tid] = 0;
         if (blockIdx.x == 0 && tid == 0) p.hdr->retry = 0;
     }
@@ -544,9 +542,11 @@ __global__ __launch_bounds__(kSThreads, 1) void demod_stream_i8(DemodArgs p)
     const uint32_t n_my = (p.tile_count - blockIdx.x + G - 1) / G; // >= 1: the grid is at most tile_count
     const uint32_t tile0 = p.tile_first + blockIdx.x;
 
-    // Two roles, two loops (a scalar branch: whole waves).  Both execute the same sequence of barriers.
-    if (wave < (uint32_t)(kSGateThreads / 64)) stream_gate_role(p, smem, tid, tile0, G, n_my);
-    else stream_lookup_role(p, smem, tid - kSGateThreads, tile0, G, n_my);
+    // Three roles, three loops (scalar branches: whole waves).  All execute the same sequence of barriers.
+    // (s_setprio 1..3 for the gate waves, the critical path of a round, measured no effect.)
+    if (wave < (uint32_t)kSGateWaves) stream_gate_role(p, smem, tid, tile0, G, n_my);
+    else if (wave < (uint32_t)(kSGateWaves + kSLookupWaves)) stream_lookup_role(p, smem, tid - kSGateThreads, tile0, G, n_my);
+    else stream_decode_role(p, smem, tid - kSGateThreads - kSLookupThreads, tile0, G, n_my);
 }
 
 hipError_t launch_demod_stream(hipStream_t s, const DemodArgs &a, uint32_t n_cu, hipEvent_t e0, hipEvent_t e1)

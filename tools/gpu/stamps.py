@@ -17,11 +17,13 @@ for _ in range(3):
 dem.fetch_counts()
 s = dem.stamps()
 rounds = max(int(s[15]), 1)
-names = ["gate (incl. barrier D)", "wait B1 (lookup waves)", "-", "-", "-", "-", "record (prev. round)", "-",
-         "lookup: conversion pass", "lookup: wait at D", "lookup: wait at B1", "lookup: decode (prev. round)"]
+names = ["gate", "gate waves: wait at R", "-", "-", "-", "-", "-", "-",
+         "lookup: conversion pass", "lookup: wait at R", "-", "-", "decode (tile i-1)", "decode waves: wait at R",
+         "record (tile i-2; zero on decode wave 0 unless it is the record wave)"]
 print(f"kernel {dem.kernel}, rounds {rounds}")
 for k, nm in enumerate(names):
     if nm != "-":
         print(f"  {nm:32s} {int(s[k]) / rounds:10.0f} cycles/round")
 print(f"  gate-wave round total            {sum(int(x) for x in s[:7]) / rounds:10.0f}")
 print(f"  lookup-wave round total          {sum(int(x) for x in s[8:12]) / rounds:10.0f}")
+print(f"  decode-wave round total          {sum(int(x) for x in s[12:15]) / rounds:10.0f}")
