@@ -252,8 +252,8 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
                 fail(ADSB_E_NODEVICE);
                 break;
             }
-            if (hipMalloc((void **)&c->lut, 65536) != hipSuccess || hipMalloc((void **)&c->stamps, 128) != hipSuccess ||
-                hipMemsetAsync(c->stamps, 0, 128, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
+            if (hipMalloc((void **)&c->lut, 65536) != hipSuccess || hipMalloc((void **)&c->stamps, 512) != hipSuccess ||
+                hipMemsetAsync(c->stamps, 0, 512, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
             e = adsbk::launch_build_lut(c->stream, c->lut);
             if (e != hipSuccess) { fail((int)e); break; }
             c->stream_grid = (uint32_t)n_cu;
@@ -271,11 +271,21 @@ extern "C" int adsb_debug_kernel(adsb_ctx *c) { return c ? (c->stream_grid ? 1 :
 
 extern "C" int adsb_debug_stamps(adsb_ctx *c, uint64_t out16[16])
 {
-    if (!c || !out16) return ADSB_E_ARG;
+    if (!c || !out16) return ADSB_E_ARG; // (slots 16..31, per-wave busy cycles, via adsb_debug_stamps_waves)
     if (!c->stamps) return ADSB_E_STATE;
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out16, c->stamps, 128, hipMemcpyDeviceToHost));
+    return ADSB_OK;
+}
+
+extern "C" int adsb_debug_stamps_waves(adsb_ctx *c, uint64_t out16[16])
+{
+    if (!c || !out16) return ADSB_E_ARG;
+    if (!c->stamps) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out16, c->stamps + 16, 128, hipMemcpyDeviceToHost));
     return ADSB_OK;
 }
 

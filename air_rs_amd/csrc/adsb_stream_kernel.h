@@ -50,7 +50,31 @@
         st_acc[k] += st_now - st_prev;                                                        \
         st_prev = st_now;                                                                     \
     } while (0)
+// per-wave busy time: from leaving a round barrier to arriving at the next
+#define WSTAMP_DECL unsigned long long ws_prev = 0, ws_busy = 0
+#define WSTAMP_LEAVE()                                                                        \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ws_prev)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#define WSTAMP_ARRIVE()                                                                       \
+    do {                                                                                      \
+        unsigned long long ws_now;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ws_now)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        ws_busy += ws_now - ws_prev;                                                          \
+    } while (0)
+#define WSTAMP_STORE(wave_global)                                                             \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && p.stamps) p.stamps[16 + (wave_global)] = ws_busy; \
+    } while (0)
 #else
+#define WSTAMP_DECL
+#define WSTAMP_LEAVE() do { } while (0)
+#define WSTAMP_ARRIVE() do { } while (0)
+#define WSTAMP_STORE(w) do { } while (0)
 #define STAMP_DECL
 #define STAMP_START() do { } while (0)
 #define STAMP(k) do { } while (0)
@@ -255,7 +279,9 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
     for (int it = 0; it < kSIters; ++it) raw[it] = u32x4{0u, 0u, 0u, 0u};
 
     STAMP_DECL;
+    WSTAMP_DECL;
     STAMP_START();
+    WSTAMP_LEAVE();
     for (uint32_t r = 0; r <= n_my + 3; ++r) {
         unsigned char *dst = smem + L::mag_off((r + 2) % 3); // buffer (r-1) % 3
         const bool more = r < n_my;
@@ -284,12 +310,15 @@ __device__ __forceinline__ void stream_lookup_role(const DemodArgs &p, unsigned 
             if (s < (uint32_t)kSMag) *reinterpret_cast<uint2 *>(dst + s) = lookup_pack(mprev);
         }
         STAMP(0); // conversion pass
+        WSTAMP_ARRIVE();
         __syncthreads(); // P1 (r = 0), P2 (r = 1), R(r - 2)
+        WSTAMP_LEAVE();
         STAMP(1); // wait for the other roles
         if (r >= 2 && r - 2 < n_my && misc[L::kCount + (r - 2) % 3] > (uint32_t)kSparseCap) dense_interlude_mirror(misc);
     }
     // nothing may be in flight into registers when the wave ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSTAMP_STORE(threadIdx.x >> 6);
 #if ADSB_STAMPS
     if (blockIdx.x == 0 && tg == 0 && p.stamps)
         for (int k = 0; k < 4; ++k) p.stamps[8 + k] = st_acc[k];
@@ -312,7 +341,9 @@ __device__ __forceinline__ void stream_decode_role(const DemodArgs &p, unsigned 
     __syncthreads(); // P1
     __syncthreads(); // P2
     STAMP_DECL;
+    WSTAMP_DECL;
     STAMP_START();
+    WSTAMP_LEAVE();
 
     // Record of tile j (local index), written by one decode wave two rounds after the tile's gate: the
     // frames the decode waves staged in LDS go to the tile's slots (its own kQuota slots, or a block of the
@@ -390,7 +421,9 @@ __device__ __forceinline__ void stream_decode_role(const DemodArgs &p, unsigned 
         STAMP(0); // decode
         if (i >= 2) record(i - 2);
         STAMP(2); // record
+        WSTAMP_ARRIVE();
         __syncthreads(); // R(i)
+        WSTAMP_LEAVE();
         STAMP(1);
         if (i < n_my && misc[L::kCount + i % 3] > (uint32_t)kSparseCap) dense_interlude_mirror(misc);
     }
@@ -398,6 +431,7 @@ __device__ __forceinline__ void stream_decode_role(const DemodArgs &p, unsigned 
     if (blockIdx.x == 0 && tg == 0 && p.stamps)
         for (int k = 0; k < 3; ++k) p.stamps[12 + k] = st_acc[k];
 #endif
+    WSTAMP_STORE(threadIdx.x >> 6);
 }
 
 // ---- role: gate waves -------------------------------------------------------------------------------------
@@ -418,7 +452,9 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
     __syncthreads(); // P1
     __syncthreads(); // P2: tile 0's magnitudes are in buffer 0
     STAMP_DECL;
+    WSTAMP_DECL;
     STAMP_START();
+    WSTAMP_LEAVE();
 
     for (uint32_t i = 0; i <= n_my + 1; ++i) {
         const bool live = i < n_my;
@@ -430,7 +466,9 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
         if (live && !ADSB_ABL_NOGATE)
             gate_phase<ST, ADSB_STREAM_GATE_GROUP, kSRun, kSGateThreads>(mag, cand, list, &misc[L::kCount + i % 3], tid, tp.n_valid);
         STAMP(0); // gate
+        WSTAMP_ARRIVE();
         __syncthreads(); // R(i)
+        WSTAMP_LEAVE();
         STAMP(1);
         if (!live) continue;
 
@@ -513,6 +551,7 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
         p.stamps[15] = n_my;
     }
 #endif
+    WSTAMP_STORE(threadIdx.x >> 6);
 }
 
 __global__ __launch_bounds__(kSThreads, 1) void demod_stream_i8(DemodArgs p)
@@ -543,7 +582,9 @@ __global__ __launch_bounds__(kSThreads, 1) void demod_stream_i8(DemodArgs p)
     const uint32_t tile0 = p.tile_first + blockIdx.x;
 
     // Three roles, three loops (scalar branches: whole waves).  All execute the same sequence of barriers.
-    // (s_setprio 1..3 for the gate waves, the critical path of a round, measured no effect.)
+    // (s_setprio for the gate waves measured no effect: per-wave stamps show the second gate wave of a SIMD
+    // taking ~900 cycles longer per round than the first; raising its priority only swaps the two -- the SIMD's
+    // issue slots are what is exhausted.)
     if (wave < (uint32_t)kSGateWaves) stream_gate_role(p, smem, tid, tile0, G, n_my);
     else if (wave < (uint32_t)(kSGateWaves + kSLookupWaves)) stream_lookup_role(p, smem, tid - kSGateThreads, tile0, G, n_my);
     else stream_decode_role(p, smem, tid - kSGateThreads - kSLookupThreads, tile0, G, n_my);

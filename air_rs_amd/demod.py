@@ -170,6 +170,11 @@ class AdsbDemod:
         L.check(self._lib.adsb_debug_stamps(self._h, out.ctypes.data), "adsb_debug_stamps")
         return out
 
+    def stamps_waves(self):
+        out = np.zeros(16, dtype=np.uint64)
+        L.check(self._lib.adsb_debug_stamps_waves(self._h, out.ctypes.data), "adsb_debug_stamps_waves")
+        return out
+
     def magnitude_table(self):
         """The streaming kernel's 64 KB table, un-swizzled: entry (Q << 8) | I (as unsigned bytes)."""
         raw = np.zeros(65536, dtype=np.uint8)

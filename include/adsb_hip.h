@@ -235,6 +235,9 @@ int adsb_debug_lut(adsb_ctx *ctx, uint8_t *table_host65536);
 /* Diagnostic builds of the streaming kernel (-DADSB_STAMPS=1) only: per-segment shader-cycle sums of
  * workgroup 0 over the last launch (zeros in a normal build). */
 int adsb_debug_stamps(adsb_ctx *ctx, uint64_t out16[16]);
+/* Same builds: cycles each of workgroup 0's 16 waves spent between leaving one round barrier and reaching
+ * the next, summed over the last launch (which wave a round waits for). */
+int adsb_debug_stamps_waves(adsb_ctx *ctx, uint64_t out16[16]);
 
 /* ---- deterministic synthetic IQ source --------------------------------------- */
 typedef struct adsb_synth_cfg {

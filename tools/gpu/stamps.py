@@ -27,3 +27,7 @@ for k, nm in enumerate(names):
 print(f"  gate-wave round total            {sum(int(x) for x in s[:7]) / rounds:10.0f}")
 print(f"  lookup-wave round total          {sum(int(x) for x in s[8:12]) / rounds:10.0f}")
 print(f"  decode-wave round total          {sum(int(x) for x in s[12:15]) / rounds:10.0f}")
+w = dem.stamps_waves()
+roles = ["gate"] * 7 + ["lookup"] * 5 + ["decode"] * 4
+print("  busy cycles per round, by wave (barrier exit -> next barrier arrival):")
+print("   " + "  ".join(f"{roles[k][0]}{k}:{int(w[k]) / rounds:.0f}" for k in range(16)))
