@@ -578,7 +578,6 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     typedef TileCfg<ST> TC; // tile length of this sample type
     typedef typename L::mag_t mag_t;
     constexpr int BPS = (ST == ADSB_SAMPLE_I8) ? 2 : 4; // bytes per IQ sample
-    constexpr int SPG = 16 / (int)sizeof(mag_t);         // magnitudes per 16-byte LDS granule
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
     mag_t *mag = reinterpret_cast<mag_t *>(smem);
