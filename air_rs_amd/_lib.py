@@ -135,6 +135,7 @@ PROTOTYPES = {
                                                _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint64)]),
     "adsb_load_c16": (C.c_int, [C.c_char_p, _P(_P(C.c_int16)), _P(C.c_size_t)]),
     "adsb_save_c16": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
+    "adsb_load_u8": (C.c_int, [C.c_char_p, _P(_P(C.c_int8)), _P(C.c_size_t)]),
     "adsb_free": (None, [C.c_void_p]),
 }
 

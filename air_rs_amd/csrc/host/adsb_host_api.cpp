@@ -2,6 +2,7 @@
 #include "../../../include/adsb_host.h"
 
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <unordered_map>
@@ -155,6 +156,29 @@ extern "C" int adsb_save_c16(const char *path, const int16_t *data, size_t n_sam
     IqBufI16 buf(src, src + n_samples);
     std::string err;
     return save_data(buf, path, err) ? ADSB_OK : ADSB_E_ARG;
+}
+
+// Raw rtl_sdr capture (`rtl_sdr -f 1090000000 -s 2000000 out.bin`): interleaved unsigned bytes I,Q around
+// 127.5.  Not a format the reference reads (utils.rs only knows .c16); the integer re-centring used here
+// is x - 128, i.e. flipping the top bit, so that the result is the library's ADSB_SAMPLE_I8 layout.
+extern "C" int adsb_load_u8(const char *path, int8_t **data, size_t *n_samples)
+{
+    if (!path || !data || !n_samples) return ADSB_E_ARG;
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) return ADSB_E_ARG;
+    if (std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return ADSB_E_ARG; }
+    const long len = std::ftell(f);
+    if (len < 0 || len % 2 != 0) { std::fclose(f); return ADSB_E_ARG; } // half a sample: like utils.rs:28-30
+    std::rewind(f);
+    unsigned char *buf = static_cast<unsigned char *>(std::malloc((size_t)len + 4));
+    if (!buf) { std::fclose(f); return ADSB_E_NOMEM; }
+    const size_t got = len ? std::fread(buf, 1, (size_t)len, f) : 0;
+    std::fclose(f);
+    if (got != (size_t)len) { std::free(buf); return ADSB_E_ARG; }
+    for (size_t k = 0; k < (size_t)len; ++k) buf[k] ^= 0x80u;
+    *data = reinterpret_cast<int8_t *>(buf);
+    *n_samples = (size_t)len / 2;
+    return ADSB_OK;
 }
 
 extern "C" void adsb_free(void *p) { std::free(p); }

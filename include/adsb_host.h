@@ -104,6 +104,10 @@ int adsb_tracker_get(const adsb_tracker *t, uint32_t icao, adsb_aircraft_summary
 /* utils.rs:22-43 / 6-20.  adsb_load_c16 allocates *data with malloc (free with adsb_free). */
 int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples);
 int adsb_save_c16(const char *path, const int16_t *data, size_t n_samples);
+/* Raw rtl_sdr capture: interleaved unsigned bytes I,Q (zero level 127.5).  Not a reference format; samples
+ * are re-centred as x - 128 into the ADSB_SAMPLE_I8 layout.  *data is malloc'ed (free with adsb_free);
+ * ADSB_E_ARG for an unreadable file or an odd length. */
+int adsb_load_u8(const char *path, int8_t **data, size_t *n_samples);
 void adsb_free(void *p);
 
 #ifdef __cplusplus

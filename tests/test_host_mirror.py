@@ -82,3 +82,21 @@ def test_c16_round_trip(lib, tmp_path):
     assert (back == data).all()
     open(p, "ab").write(b"\x00")  # length not divisible by 4 is rejected (utils.rs:28-30)
     assert L.adsb_load_c16(p, C.byref(ptr), C.byref(n)) != 0
+
+
+def test_raw_u8_capture_loads_as_i8(lib, tmp_path):
+    """rtl_sdr's unsigned-byte capture (not a reference format): x - 128 into the ADSB_SAMPLE_I8 layout."""
+    import ctypes as C
+    from air_rs_amd import _lib
+    L = _lib.load()
+    raw = np.arange(256, dtype=np.uint8)
+    p = str(tmp_path / "x.bin").encode()
+    open(p, "wb").write(raw.tobytes())
+    ptr, n = C.POINTER(C.c_int8)(), C.c_size_t()
+    assert L.adsb_load_u8(p, C.byref(ptr), C.byref(n)) == 0 and n.value == 128
+    back = np.ctypeslib.as_array(ptr, shape=(256,)).copy()
+    L.adsb_free(ptr)
+    assert (back.astype(np.int16) == raw.astype(np.int16) - 128).all()
+    open(p, "ab").write(b"\x00")  # half a sample
+    assert L.adsb_load_u8(p, C.byref(ptr), C.byref(n)) != 0
+    assert L.adsb_load_u8(str(tmp_path / "missing.bin").encode(), C.byref(ptr), C.byref(n)) != 0
