@@ -132,19 +132,35 @@ template <int MAGMODE> __device__ __forceinline__ float mag_root_i8(int n_plus_2
 }
 
 // 8 consecutive i8 IQ samples (16 bytes) -> 8 magnitudes packed as bytes in two dwords.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int MAGMODE>
 __device__ __forceinline__ void mags8_i8(u32x4 v, uint32_t &lo, uint32_t &hi)
 {
     int n[8];
     dot4x8_sacc(v, 0x4B000000, n);
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[0]), 0, 0u);
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[1]), 1, lo);
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[2]), 2, lo);
-    lo = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[3]), 3, lo);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[4]), 0, 0u);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[5]), 1, hi);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[6]), 2, hi);
-    hi = __builtin_amdgcn_cvt_pk_u8_f32(mag_root_i8<MAGMODE>(n[7]), 3, hi);
+    // n + 0.5 for two samples per instruction (v_pk_add_f32; see mag_root_i8 for the constant)
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        f32x2 t = {__builtin_bit_cast(float, n[k]), __builtin_bit_cast(float, n[k + 1])};
+        t = t - (f32x2){8388607.5f, 8388607.5f};
+        f[k] = t.x;
+        f[k + 1] = t.y;
+    }
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        r[k] = __builtin_amdgcn_sqrtf(f[k]);
+        if (MAGMODE == 2) r[k] -= 0.5f; // converter rounds to nearest: land in (k-0.5, k+0.5)
+    }
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(r[0], 0, 0u);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(r[1], 1, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(r[2], 2, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(r[3], 3, lo);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(r[4], 0, 0u);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(r[5], 1, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(r[6], 2, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(r[7], 3, hi);
 }
 
 // floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): n by one v_dot2_i32_i16, a float estimate biased

@@ -112,9 +112,16 @@
 #define I_maxu16sdwa(R) "v_max_u16_sdwa " R ", " R ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n"
 #define I_dot2(R) "v_dot2_i32_i16 " R ", " R ", %8, %9\n"
 #define I_dot4u(R) "v_dot4_u32_u8 " R ", " R ", %8, %9\n"
+#define I_addsdwapres(R) "v_add_f32_sdwa " R ", " R ", %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+#define I_addsdwapad(R) "v_add_f32_sdwa " R ", " R ", %8 dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+#define I_addsdwadw(R) "v_add_f32_sdwa " R ", " R ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define I_mix_addpres_and(R) "v_add_f32_sdwa " R ", " R ", %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\nv_and_b32 " R ", " R ", %9\n"
+#define I_addsdwapres3(R) "v_add_f32_sdwa " R ", %9, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+#define I_addsdwapad3(R) "v_add_f32_sdwa " R ", %9, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+#define I_mix_pres3_pkmax(R) "v_add_f32_sdwa " R ", %9, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\nv_pk_max_u16 " R ", " R ", %8\n"
 #define LIST(X) X(or) X(xor) X(addu32) X(subu32) X(lshr) X(lshl) X(maxu16) X(minu16) X(maxf16) X(cmpu32) \
     X(cmpf16) X(cmpf32) X(mulf32) X(subf32) X(bfi) X(add3) X(or3) X(cndv) X(minf32) X(addf16) X(pkaddf16) \
-    X(mix_sqrt_pkmax) X(mix_sqrt_and) X(mix_pkmax_and) X(mix_pkmax_add) X(cmpsdwab) X(maxu16sdwa) X(dot2) X(dot4u)
+    X(mix_sqrt_pkmax) X(mix_sqrt_and) X(mix_pkmax_and) X(mix_pkmax_add) X(cmpsdwab) X(maxu16sdwa) X(dot2) X(dot4u) X(addsdwapres) X(addsdwapad) X(addsdwadw) X(mix_addpres_and) X(addsdwapres3) X(addsdwapad3) X(mix_pres3_pkmax)
 
 #define MK(N) DEFK(N, I_##N)
 LIST(MK)
