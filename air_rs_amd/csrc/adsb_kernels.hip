@@ -163,41 +163,63 @@ __device__ __forceinline__ void mags8_i8(u32x4 v, uint32_t &lo, uint32_t &hi)
     hi = __builtin_amdgcn_cvt_pk_u8_f32(r[7], 3, hi);
 }
 
-// floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): n by one v_dot2_i32_i16, a float estimate biased
-// upward so that it can only be right or one too high, and one exact integer correction.
+// floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): n by one v_dot2_i32_i16, a float estimate rounded to
+// the nearest integer, and one exact integer correction.
 // Error budget of sqrtf((float)n) at s = sqrt(n) <= 46341: conversion to float 2^-24 relative (2^-25 after
-// the root), v_sqrt_f32 one ulp (2^-23), the addition of the bias half an ulp of the sum (2^-9):
-// |e| <= 46341 * 1.5e-7 + 0.002 < 0.0089 < bias = 3/256.  So est is in (s, s + 0.021): floor(est) is
-// floor(s) or floor(s) + 1, and r * r > n tells which (r <= 46341: r * r < 2^32).
-__device__ __forceinline__ uint32_t mag_i16_root(uint32_t n)
+// the root), v_sqrt_f32 one ulp (2^-23): |e| <= 46341 * 1.5e-7 < 0.007.  v_cvt_rpi_i32_f32 is floor(x + 0.5),
+// so the estimate is floor(s) or floor(s) + 1 (either of them when the fraction of s is within 0.007 of one
+// half), and r * r > n tells which (r <= 46341: r * r < 2^32).
+// gfx950 does not interlock a transcendental result against the next VALU instruction (one wait state is
+// required) and hipcc pads nothing inside or around inline asm: the s_nop between v_sqrt_f32 and its reader
+// below is load-bearing.
+__device__ __forceinline__ uint32_t mag_i16_fix(uint32_t r, uint32_t n)
 {
-    uint32_t r = (uint32_t)(__builtin_amdgcn_sqrtf((float)n) + 0.01171875f);
-    r -= (__umul24(r, r) > n) ? 1u : 0u; // r < 2^24: the 24-bit multiply is exact and full rate
-    return r;
+    return r - ((__umul24(r, r) > n) ? 1u : 0u); // r < 2^24: the 24-bit multiply is exact and full rate
 }
 __device__ __forceinline__ uint32_t mag_i16(uint32_t iq)
 {
-    uint32_t n; // 2^31 for (-32768, -32768): the i32 result wraps to the right bits
+    uint32_t n, r; // n = 2^31 for (-32768, -32768): the i32 result wraps to the right bits
     // (VOP3P form with the inline constant 0 as accumulator: for the builtin hipcc picks v_dot2c, which needs
     // a v_mov per call to preload it; gfx950 wants 3 wait states between a DOT and a VALU reading it)
-    asm("v_dot2_i32_i16 %0, %1, %1, 0\n\ts_nop 2" : "=v"(n) : "v"(iq));
-    return mag_i16_root(n);
+    asm("v_dot2_i32_i16 %0, %2, %2, 0\n\t"
+        "s_nop 2\n\t"
+        "v_cvt_f32_u32 %1, %0\n\t"
+        "v_sqrt_f32 %1, %1\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_rpi_i32_f32 %1, %1"
+        : "=&v"(n), "=&v"(r)
+        : "v"(iq));
+    return mag_i16_fix(r, n);
 }
-// four samples (one 16-byte load): the dots issue back to back, one wait for all of them
-__device__ __forceinline__ void mags4_i16(u32x4 v, uint32_t m[4])
+// four samples (one 16-byte load) -> two words of packed u16 magnitudes; each group of four like instructions
+// issues back to back, which also covers the wait states between a group and the next
+__device__ __forceinline__ void mags4_i16(u32x4 v, uint32_t &lo, uint32_t &hi)
 {
-    uint32_t n0, n1, n2, n3;
-    asm("v_dot2_i32_i16 %0, %4, %4, 0\n\t"
-        "v_dot2_i32_i16 %1, %5, %5, 0\n\t"
-        "v_dot2_i32_i16 %2, %6, %6, 0\n\t"
-        "v_dot2_i32_i16 %3, %7, %7, 0\n\t"
-        "s_nop 2"
-        : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+    uint32_t n0, n1, n2, n3, r0, r1, r2, r3;
+    asm("v_dot2_i32_i16 %0, %8, %8, 0\n\t"
+        "v_dot2_i32_i16 %1, %9, %9, 0\n\t"
+        "v_dot2_i32_i16 %2, %10, %10, 0\n\t"
+        "v_dot2_i32_i16 %3, %11, %11, 0\n\t"
+        "s_nop 2\n\t"
+        "v_cvt_f32_u32 %4, %0\n\t"
+        "v_cvt_f32_u32 %5, %1\n\t"
+        "v_cvt_f32_u32 %6, %2\n\t"
+        "v_cvt_f32_u32 %7, %3\n\t"
+        "v_sqrt_f32 %4, %4\n\t"
+        "v_sqrt_f32 %5, %5\n\t"
+        "v_sqrt_f32 %6, %6\n\t"
+        "v_sqrt_f32 %7, %7\n\t"
+        "v_cvt_rpi_i32_f32 %4, %4\n\t"
+        "v_cvt_rpi_i32_f32 %5, %5\n\t"
+        "v_cvt_rpi_i32_f32 %6, %6\n\t"
+        "s_nop 0\n\t"
+        "v_cvt_rpi_i32_f32 %7, %7\n\t"
+        "s_nop 0"
+        : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
         : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-    m[0] = mag_i16_root(n0);
-    m[1] = mag_i16_root(n1);
-    m[2] = mag_i16_root(n2);
-    m[3] = mag_i16_root(n3);
+    // low halves of two registers into one (one v_perm; the magnitudes are < 2^16)
+    lo = __builtin_amdgcn_perm(mag_i16_fix(r1, n1), mag_i16_fix(r0, n0), 0x05040100u);
+    hi = __builtin_amdgcn_perm(mag_i16_fix(r3, n3), mag_i16_fix(r2, n2), 0x05040100u);
 }
 
 // ---- probe: how does v_cvt_pk_u8_f32 round here? --------------------------------------------
@@ -644,14 +666,21 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 }
             } else {
                 constexpr int kIters = (TC::kMagT + kThreads * 4 - 1) / (kThreads * 4); // 17 (33 with 64-offset runs)
+                // all of the tile's loads in flight before the first magnitude, like the i8 branch
+                u32x4 raw[kIters];
+                const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 4;
+#pragma unroll
+                for (int it = 0; it < kIters; ++it)
+                    if ((uint32_t)it * (kThreads * 4) + wave_s0 < (uint32_t)TC::kMagT)
+                        raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
 #pragma unroll
                 for (int it = 0; it < kIters; ++it) {
-                    uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
-                    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, s * 4, 0, 0);
-                    uint32_t m[4];
-                    mags4_i16(v, m);
-                    if (s < (uint32_t)TC::kMagT)
-                        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                    if ((uint32_t)it * (kThreads * 4) + wave_s0 < (uint32_t)TC::kMagT) {
+                        const uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
+                        uint32_t lo, hi;
+                        mags4_i16(raw[it], lo, hi);
+                        if (s < (uint32_t)TC::kMagT) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+                    }
                 }
             }
         }
