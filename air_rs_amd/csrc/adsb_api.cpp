@@ -401,8 +401,11 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     }
     HIPCHK(adsbk::launch_gather(c->aux, compact_args(c, r, i % 3u, (int)((i + 2u) % 3u), 0, c->last_tiles, false),
                                 ev ? ev[2] : nullptr, ev ? ev[3] : nullptr));
-    HIPCHK(hipEventRecord(r.g_done, c->aux));
-    r.g_pending = true;
+    // (same stream: in-order already; adsb_stream_wait_results records the event when somebody asks for it)
+    if (c->own_aux) {
+        HIPCHK(hipEventRecord(r.g_done, c->aux));
+        r.g_pending = true;
+    }
     c->last_out = c->ext_blob ? reinterpret_cast<adsb_frame *>(static_cast<char *>(c->ext_blob) + 32) : r.out;
     c->last_cap = c->ext_blob ? (uint32_t)std::min<size_t>(c->ext_frames, c->cfg.max_out) : (uint32_t)c->cfg.max_out;
     c->last = i & 1u;
@@ -631,6 +634,7 @@ extern "C" int adsb_stream_wait_results(adsb_ctx *c, void *stream)
     if (!c) return ADSB_E_ARG;
     if (!c->launched) return ADSB_E_STATE;
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->own_aux) HIPCHK(hipEventRecord(c->rs[c->last].g_done, c->aux)); // tail of the in-order stream
     HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->rs[c->last].g_done, 0));
     return ADSB_OK;
 }
