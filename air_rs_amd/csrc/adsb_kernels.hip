@@ -881,30 +881,36 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
     }
     const uint32_t t = a.tile_first + blockIdx.x * 4 + wave;
     if (t >= a.tile_first + a.tile_count) return;
+    // the tile's own record and the counts its position is summed from are independent loads: issue them
+    // together (one memory latency instead of two on this wave's critical path)
     const Seg e = a.seg[t];
-    if (e.valid == 0) return;
     uint32_t pos = a.out_start ? a.out_start[t] : tile_prefix(a, t, lane);
+    if (e.valid == 0) return;
     if (pos >= a.max_out) return;
     if (e.base == kNoBase) { // its slots were dropped but its frames are wanted: host re-plans
         if (lane == 0) atomicOr(&a.hdr->retry, 1u);
         return;
     }
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.slots + e.base);
+    const uint2 *src = reinterpret_cast<const uint2 *>(a.slots + e.base); // 24-byte records, 8-byte aligned
     for (uint32_t i0 = 0; i0 < e.cand; i0 += 64) {
         const uint32_t i = i0 + lane;
         uint32_t w[6] = {0, 0, 0, 0, 0, 0xFF0000u};
         if (i < e.cand) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) w[k] = src[(size_t)i * 6 + k];
+            for (int k = 0; k < 3; ++k) {
+                const uint2 v = src[(size_t)i * 3 + k];
+                w[2 * k] = v.x;
+                w[2 * k + 1] = v.y;
+            }
         }
         const bool ok = (i < e.cand) && (((w[5] >> 16) & 0xFFu) != 0xFFu);
         const unsigned long long m = __ballot(ok);
         const uint32_t before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
         const uint32_t dst = pos + before;
         if (ok && dst < a.max_out) {
-            uint32_t *d = reinterpret_cast<uint32_t *>(a.out + dst);
+            uint2 *d = reinterpret_cast<uint2 *>(a.out + dst);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) d[k] = w[k];
+            for (int k = 0; k < 3; ++k) d[k] = make_uint2(w[2 * k], w[2 * k + 1]);
         }
         pos += (uint32_t)__builtin_popcountll(m);
     }
