@@ -92,6 +92,13 @@ def main():
                     help="exercise the multi-rank frame-list gather even with one rank (testing)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a five-line version banner to fd 1 when the first
+    # communicator comes up (native code, not Python): keep the real stdout aside for the JSON line and point
+    # fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     if args.kernel != "default":
         os.environ["ADSB_KERNEL"] = args.kernel  # read by adsb_create
     rank = int(os.environ.get("RANK", "0"))
@@ -259,7 +266,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and bps == 2 and nch == 1:
             sample = iq.cpu().numpy().reshape(-1, 2)  # the whole buffer: ~6-10 s on one host core
             out["cpu_baseline"] = cpu_baseline(sample)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     dem.close()
     if dist:
         dist.destroy_process_group()
