@@ -853,7 +853,7 @@ __device__ __forceinline__ uint32_t tile_prefix(const CompactArgs &a, uint32_t t
     return sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;
 }
 
-// gather: one wave per tile copies its valid slots, in slot (= offset) order, to the final list.
+// gather: one wave per four tiles copies their valid slots, in slot (= offset) order, to the final list.
 // Workgroup 0 also writes the header / per-channel counts and re-arms the pool allocator; all
 // workgroups clear the other parity's group counters for the next launch.
 __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
@@ -890,46 +890,102 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
             }
         }
     }
-    const uint32_t t = a.tile_first + blockIdx.x * 4 + wave;
-    if (t >= a.tile_first + a.tile_count) return;
-    // the tile's own record and the counts its position is summed from are independent loads: issue them
-    // together (one memory latency instead of two on this wave's critical path)
-    const Seg e = a.seg[t];
-    uint32_t pos = a.out_start ? a.out_start[t] : tile_prefix(a, t, lane);
-    if (e.valid == 0) return;
-    if (pos >= a.max_out) return;
-    if (e.base == kNoBase) { // its slots were dropped but its frames are wanted: host re-plans
-        if (lane == 0) atomicOr(&a.hdr->retry, 1u);
+    // Four consecutive tiles per wave (a quarter of the waves, one round of them per CU): the position of the
+    // first comes from the group counters (wave-cooperative), the others follow by adding the valid counts.
+    const uint32_t t_end = a.tile_first + a.tile_count;
+    const uint32_t t0 = a.tile_first + (blockIdx.x * 4 + wave) * 4;
+    if (t0 >= t_end) return;
+    Seg mine;
+    mine.base = kNoBase; mine.cand = 0; mine.valid = 0; mine.pad = 0;
+    if (lane < 4 && t0 + lane < t_end) mine = a.seg[t0 + lane];
+    // the tiles' own records and the counts the position is summed from are independent loads: issued together
+    uint32_t pos0 = a.out_start ? 0u : tile_prefix(a, t0, lane);
+    uint32_t base[4], cand[4], valid[4], pos[4], maxcand = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        base[k] = __shfl(mine.base, k, 64);
+        cand[k] = __shfl(mine.cand, k, 64);
+        valid[k] = __shfl(mine.valid, k, 64);
+    }
+    {
+        unsigned long long run = pos0; // (saturating like tile_prefix)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pos[k] = a.out_start ? ((t0 + k < t_end) ? a.out_start[t0 + k] : 0xFFFFFFFFu)
+                                 : (run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run);
+            run += valid[k];
+            if (valid[k] == 0 || pos[k] >= a.max_out) cand[k] = 0; // nothing of this tile is wanted
+            if (cand[k] && base[k] == kNoBase) { // its slots were dropped but its frames are wanted: host re-plans
+                if (lane == 0) atomicOr(&a.hdr->retry, 1u);
+                cand[k] = 0;
+            }
+            maxcand = cand[k] > maxcand ? cand[k] : maxcand;
+        }
+    }
+    if (maxcand == 0) return;
+    if (maxcand <= 64) {
+        // the usual case: 16 lanes per tile, all four tiles side by side
+        const uint32_t g = lane >> 4, l = lane & 15;
+        const uint32_t gb = g == 0 ? base[0] : g == 1 ? base[1] : g == 2 ? base[2] : base[3];
+        const uint32_t gc = g == 0 ? cand[0] : g == 1 ? cand[1] : g == 2 ? cand[2] : cand[3];
+        uint32_t gp = g == 0 ? pos[0] : g == 1 ? pos[1] : g == 2 ? pos[2] : pos[3];
+        const uint2 *src = reinterpret_cast<const uint2 *>(a.slots + (gc ? gb : 0u)); // 24-byte records, 8-byte aligned
+        for (uint32_t i0 = 0; i0 < maxcand; i0 += 16) { // (wave-uniform trip count)
+            const uint32_t i = i0 + l;
+            uint32_t w[6] = {0, 0, 0, 0, 0, 0xFF0000u};
+            if (i < gc) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint2 v = src[(size_t)i * 3 + k];
+                    w[2 * k] = v.x;
+                    w[2 * k + 1] = v.y;
+                }
+            }
+            const bool ok = (i < gc) && (((w[5] >> 16) & 0xFFu) != 0xFFu);
+            const uint32_t m = (uint32_t)(__ballot(ok) >> (16 * g)) & 0xFFFFu;
+            const uint32_t dst = gp + (uint32_t)__builtin_popcount(m & ((1u << l) - 1u));
+            if (ok && dst < a.max_out) {
+                uint2 *d = reinterpret_cast<uint2 *>(a.out + dst);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d[k] = make_uint2(w[2 * k], w[2 * k + 1]);
+            }
+            gp += (uint32_t)__builtin_popcount(m);
+        }
         return;
     }
-    const uint2 *src = reinterpret_cast<const uint2 *>(a.slots + e.base); // 24-byte records, 8-byte aligned
-    for (uint32_t i0 = 0; i0 < e.cand; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        uint32_t w[6] = {0, 0, 0, 0, 0, 0xFF0000u};
-        if (i < e.cand) {
+    // a tile with many survivors (coarse or constant input): the whole wave takes the tiles one after the other
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint2 v = src[(size_t)i * 3 + k];
-                w[2 * k] = v.x;
-                w[2 * k + 1] = v.y;
+    for (int k = 0; k < 4; ++k) {
+        if (cand[k] == 0) continue;
+        const uint2 *src = reinterpret_cast<const uint2 *>(a.slots + base[k]);
+        uint32_t p = pos[k];
+        for (uint32_t i0 = 0; i0 < cand[k]; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint32_t w[6] = {0, 0, 0, 0, 0, 0xFF0000u};
+            if (i < cand[k]) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const uint2 v = src[(size_t)i * 3 + q];
+                    w[2 * q] = v.x;
+                    w[2 * q + 1] = v.y;
+                }
             }
-        }
-        const bool ok = (i < e.cand) && (((w[5] >> 16) & 0xFFu) != 0xFFu);
-        const unsigned long long m = __ballot(ok);
-        const uint32_t before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        const uint32_t dst = pos + before;
-        if (ok && dst < a.max_out) {
-            uint2 *d = reinterpret_cast<uint2 *>(a.out + dst);
+            const bool ok = (i < cand[k]) && (((w[5] >> 16) & 0xFFu) != 0xFFu);
+            const unsigned long long m = __ballot(ok);
+            const uint32_t dst = p + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (ok && dst < a.max_out) {
+                uint2 *d = reinterpret_cast<uint2 *>(a.out + dst);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) d[k] = make_uint2(w[2 * k], w[2 * k + 1]);
+                for (int q = 0; q < 3; ++q) d[q] = make_uint2(w[2 * q], w[2 * q + 1]);
+            }
+            p += (uint32_t)__builtin_popcountll(m);
         }
-        pos += (uint32_t)__builtin_popcountll(m);
     }
 }
 
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0, hipEvent_t e1)
 {
-    uint32_t blocks = (a.tile_count + 3) / 4;
+    uint32_t blocks = (a.tile_count + 15) / 16; // 4 waves x 4 tiles
     if (blocks == 0) blocks = 1; // the header still has to be written
     hipExtLaunchKernelGGL(gather_tiles, dim3(blocks), dim3(256), 0, s, e0, e1, 0, a);
     return hipGetLastError();
