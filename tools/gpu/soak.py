@@ -21,7 +21,11 @@ for kern in ("stream", "tiles"):
 ctx[(A.ADSB_SAMPLE_I16, "tiles")] = A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 22, max_out=1 << 19)
 t0 = time.time()
 runs = fails = frames_total = 0
+t_note = t0
 while time.time() - t0 < args.seconds:
+    if time.time() - t_note > 30:      # a silent run is taken for a hung one on the GPU box
+        t_note = time.time()
+        print(f"  ... {runs} buffers, {fails} mismatches after {t_note - t0:.0f} s", flush=True)
     st = A.ADSB_SAMPLE_I8 if rng.random() < 0.7 else A.ADSB_SAMPLE_I16
     kern = "tiles" if st == A.ADSB_SAMPLE_I16 else ("stream" if rng.random() < 0.5 else "tiles")
     n = int(rng.choice([rng.integers(240, 4000), rng.integers(4000, 200000), rng.integers(200000, 3000000)]))
