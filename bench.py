@@ -131,10 +131,7 @@ def main():
                       max_channels=nch, stream=stream.cuda_stream, host_staging=False)
     if st == A.ADSB_SAMPLE_I16:
         cfg.amp_shift = 6
-    # (ADSB_BENCH_ALLOC_BYTES: allocate a larger block and use its head -- an experiment on how the size of the
-    # allocation, i.e. the page-table fragment size, affects the kernel)
-    iq_block = torch.empty(max(n * bps, int(os.environ.get("ADSB_BENCH_ALLOC_BYTES", "0"))), dtype=torch.int8, device="cuda")
-    iq = iq_block[:n * bps]
+    iq = torch.empty(n * bps, dtype=torch.int8, device="cuda")
     if nch == 1:
         dem.synth_fill_device(cfg, 0, first, n, iq.data_ptr())
     else:
