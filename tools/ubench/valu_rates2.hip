@@ -131,6 +131,37 @@ struct Ent { const char *name; kfn fn; };
 #define EN(N) {#N, k_##N},
 static Ent ents[] = {LIST(EN)};
 
+
+// Do transcendentals of one wave overlap the ordinary VALU work of ANOTHER wave on the same SIMD?  512 threads:
+// waves w and w + 4 share SIMD w.  Waves 0-3 run v_sqrt_f32 only, waves 4-7 v_pk_max_u16 only (same count);
+// out[2] / out[3] = cycles of a sqrt wave / a pk_max wave.  Alone: 8 and 4 cycles per instruction.
+__global__ __launch_bounds__(512) void k_mixwaves(uint64_t *out, uint32_t seed, int mode)
+{
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, b = seed * 31 + 7;
+    const bool trans = (threadIdx.x >> 8) == 0; // waves 0-3
+    const bool idle = (mode == 1 && !trans) || (mode == 2 && trans);
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    if (!idle) {
+        if (trans) {
+            for (int i = 0; i < ITERS; ++i)
+                asm volatile("v_sqrt_f32 %0, %0\nv_sqrt_f32 %1, %1\nv_sqrt_f32 %2, %2\nv_sqrt_f32 %3, %3\n"
+                             "v_sqrt_f32 %0, %0\nv_sqrt_f32 %1, %1\nv_sqrt_f32 %2, %2\nv_sqrt_f32 %3, %3\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else {
+            for (int i = 0; i < ITERS; ++i)
+                asm volatile("v_pk_max_u16 %0, %0, %4\nv_pk_max_u16 %1, %1, %4\nv_pk_max_u16 %2, %2, %4\nv_pk_max_u16 %3, %3, %4\n"
+                             "v_pk_max_u16 %0, %0, %4\nv_pk_max_u16 %1, %1, %4\nv_pk_max_u16 %2, %2, %4\nv_pk_max_u16 %3, %3, %4\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        }
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345) out[1] = a0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = t1 - t0;
+    if (blockIdx.x == 0 && threadIdx.x == 256) out[3] = t1 - t0;
+}
+
 int main()
 {
     uint64_t *d;
@@ -166,6 +197,16 @@ int main()
         double per_simd_per_us = winstr / (ncu * 4.0) / (ms * 1e3);
         printf("%-12s %10.2f %10.2f %10.2f   chip: %8.1f wave-instr/us/SIMD (%.2f cycles each at 2.4 GHz)\n", e.name, r[0], r[1], r[2],
                per_simd_per_us, 2400.0 / per_simd_per_us);
+    }
+    for (int mode = 0; mode < 3; ++mode) {
+        uint64_t h[4] = {0, 0, 0, 0};
+        hipMemset(d, 0, 64);
+        hipLaunchKernelGGL(k_mixwaves, dim3(ncu), dim3(512), 0, 0, d, 12345u, mode);
+        hipLaunchKernelGGL(k_mixwaves, dim3(ncu), dim3(512), 0, 0, d, 12345u, mode);
+        hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
+        printf("mixwaves mode %d (%s): sqrt wave %.2f cycles per instruction, pk_max wave %.2f\n", mode,
+               mode == 0 ? "both kinds on every SIMD" : mode == 1 ? "sqrt waves only" : "pk_max waves only",
+               (double)h[2] / (ITERS * 8.0), (double)h[3] / (ITERS * 8.0));
     }
     return 0;
 }
