@@ -732,7 +732,9 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         }
 
         // Frame slots: the tile's own fixed region when the survivors fit (no atomics), otherwise
-        // one allocation from the shared pool.
+        // one allocation from the shared pool.  In the usual case (a handful of survivors) every thread knows
+        // the base without asking tid 0, and the list is complete since the barrier above: no barrier (c).
+        const bool simple = !dense && total <= kQuota;
         if (tid == 0) {
             uint32_t b = tile * kQuota;
             if (total > kQuota) {
@@ -759,8 +761,8 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                     }
                 }
             }
-            __syncthreads();
-            const uint32_t base_slot = misc[9];
+            if (!simple) __syncthreads();
+            const uint32_t base_slot = simple ? tile * kQuota : misc[9];
             const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
             const uint32_t g = tid >> 4, l = tid & 15;
             for (uint32_t r = 0; r < ncl; r += 16) {
@@ -791,10 +793,10 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
             }
             __syncthreads();
         }
-        if (total == 0) __syncthreads(); // pair with the barrier inside the loop for misc[8]/[9]
+        // (total == 0: nothing was added to misc[8] since tid 0 cleared it before the phase-1 barrier)
         if (tid == 0) {
             Seg e;
-            e.base = misc[9];
+            e.base = simple ? tile * kQuota : misc[9];
             e.cand = total;
             e.valid = misc[8];
             e.pad = 0;
