@@ -142,6 +142,30 @@ PROTOTYPES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must not hold two HIP runtimes: the second one to initialise finds no device.
+
+    A PyTorch-ROCm wheel ships its own libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's) and
+    loads it by file name, so `import torch` AFTER libadsb_hip.so has pulled in the system copy gives the process
+    a second runtime ("No HIP GPUs are available"), while the other order is fine: the loader then binds
+    libadsb_hip.so's NEEDED libamdhip64.so.7 to the copy that is already there.  When a torch wheel with a
+    bundled runtime is installed, load that copy first, so that whichever of the two is imported first they
+    share one runtime.  torch itself is not imported.  ADSB_HIP_SYSTEM_RUNTIME=1 opts out.
+    """
+    if os.environ.get("ADSB_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # best effort: without it the import order decides, as before
+
+
 def load():
     """Load the HIP library; raises if it has not been built (no fallback)."""
     global _lib
@@ -151,6 +175,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with ./build.sh (or __graft_entry__.build()). "
             "air_rs_amd has no CPU fallback for the demodulation path.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

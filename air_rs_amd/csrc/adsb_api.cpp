@@ -72,6 +72,8 @@ struct adsb_ctx {
     uint8_t *lut = nullptr;         // i8 streaming kernel: 64 KB floor(sqrt(I^2+Q^2)) table (swizzled index)
     unsigned long long *stamps = nullptr; // 16 cycle counters (diagnostic builds of the streaming kernel)
     uint32_t stream_grid = 0;       // persistent workgroups of the streaming kernel (= CUs); 0: tile kernel
+    uint32_t *tickets = nullptr;    // tile-ticket counters of the persistent tile kernel
+    uint32_t persist_grid = 0;      // its grid: resident workgroup slots (CUs x 4)
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
 
@@ -149,6 +151,7 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     (void)hipFree(c->scratch);
     (void)hipFree(c->lut);
     (void)hipFree(c->stamps);
+    (void)hipFree(c->tickets);
     (void)hipFree(c->grp);
     if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
@@ -246,6 +249,17 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         else if (probe[1] == want) c->mag_mode = 1;
         else c->mag_mode = 2;
         if (const char *force = getenv("ADSB_FORCE_MAG_MODE")) c->mag_mode = atoi(force) % 3;
+        {
+            int n_cu = 0;
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) {
+                fail(ADSB_E_NODEVICE);
+                break;
+            }
+            const size_t tb = sizeof(uint32_t) * 9 * adsbk::kTicketStride;
+            if (hipMalloc((void **)&c->tickets, tb) != hipSuccess || hipMemsetAsync(c->tickets, 0, tb, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
+            c->persist_grid = (uint32_t)n_cu * 4u;
+            if (const char *g = getenv("ADSB_PERSIST_GRID")) { int v = atoi(g); if (v > 0) c->persist_grid = (uint32_t)v; }
+        }
         if (want_stream) {
             int n_cu = 0;
             if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) {
@@ -323,6 +337,8 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.lut = c->lut;
     a.stream_grid = c->stream_grid;
     a.stamps = c->stamps;
+    a.tickets = c->tickets;
+    a.persist_grid = c->persist_grid;
     return a;
 }
 

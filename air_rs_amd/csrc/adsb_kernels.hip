@@ -73,6 +73,7 @@ template <int ST> __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_
     return pkmin(pkmin(a, b), c);
 }
 
+// [phase:1 magnitude (helpers)]  (markers read by tools/isa_slots.py)
 // Eight I^2+Q^2 sums (one 16-byte load = 8 samples) as VOP3P v_dot4_i32_i8 with the accumulator in
 // an SGPR.  Why asm: for the builtin hipcc picks the VOP2 v_dot4c form, which needs a v_mov per
 // call to preload the constant accumulator.  gfx950 needs 3 wait states between a DOT writing a
@@ -163,6 +164,45 @@ __device__ __forceinline__ void mags8_i8(u32x4 v, uint32_t &lo, uint32_t &hi)
     hi = __builtin_amdgcn_cvt_pk_u8_f32(r[7], 3, hi);
 }
 
+// ---- i8 magnitudes from format-converting loads ---------------------------------------------------------
+// The memory pipeline can unpack and convert on the way in: a typed buffer load (data format 8_8_8_8, numeric
+// format SSCALED, D16) returns four consecutive i8 as four f16 VALUES in two VGPRs -- one IQ sample per VGPR
+// as an (I, Q) f16 pair, exact for |x| <= 128.  One v_dot2_f32_f16 with the inline constant 0.5 as accumulator
+// then gives I^2 + Q^2 + 0.5 as f32 (exact: every product and the sum are integers + 0.5 below 2^24): the
+// v_and, the integer dot product and the 2^23 subtraction of the untyped path are gone (4 instead of 5.5 issue
+// slots per sample).  No clang builtin exists for the typed load; the LLVM intrinsic is declared by its name
+// (format = dfmt | nfmt << 4: BUF_DATA_FORMAT_8_8_8_8 = 10, BUF_NUM_FORMAT_SSCALED = 3).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ f16x4 tbuffer_load_v4f16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int format, int aux)
+    __asm("llvm.amdgcn.raw.ptr.tbuffer.load.v4f16");
+constexpr int kFmtI8x4ToF16 = 10 | (3 << 4);
+
+// Eight samples (four typed loads) -> eight n + 0.5.  VOP3P form with the constant as src2 (for the builtin hipcc
+// picks v_dot2c, which needs a v_mov per call to preload the accumulator); 3 wait states between a DOT and a
+// different VALU reading its result, and hipcc pads nothing for asm: the block ends in s_nop 2.
+__device__ __forceinline__ void dot2x8_f16(const uint32_t h[8], float f[8])
+{
+    asm("v_dot2_f32_f16 %0, %8, %8, 0.5\n\t"
+        "v_dot2_f32_f16 %1, %9, %9, 0.5\n\t"
+        "v_dot2_f32_f16 %2, %10, %10, 0.5\n\t"
+        "v_dot2_f32_f16 %3, %11, %11, 0.5\n\t"
+        "v_dot2_f32_f16 %4, %12, %12, 0.5\n\t"
+        "v_dot2_f32_f16 %5, %13, %13, 0.5\n\t"
+        "v_dot2_f32_f16 %6, %14, %14, 0.5\n\t"
+        "v_dot2_f32_f16 %7, %15, %15, 0.5\n\t"
+        "s_nop 2"
+        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(h[4]), "v"(h[5]), "v"(h[6]), "v"(h[7]));
+}
+// two samples of one typed load -> two magnitude bytes (low half of the result)
+template <int MAGMODE> __device__ __forceinline__ uint32_t mags2_from_root(float f0, float f1)
+{
+    float r0 = __builtin_amdgcn_sqrtf(f0), r1 = __builtin_amdgcn_sqrtf(f1);
+    if (MAGMODE == 2) { r0 -= 0.5f; r1 -= 0.5f; }
+    uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(r0, 0, 0u);
+    return __builtin_amdgcn_cvt_pk_u8_f32(r1, 1, w);
+}
+
 // floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): n by one v_dot2_i32_i16, a float estimate rounded to
 // the nearest integer, and one exact integer correction.
 // Error budget of sqrtf((float)n) at s = sqrt(n) <= 46341: conversion to float 2^-24 relative (2^-25 after
@@ -222,6 +262,7 @@ __device__ __forceinline__ void mags4_i16(u32x4 v, uint32_t &lo, uint32_t &hi)
     hi = __builtin_amdgcn_perm(mag_i16_fix(r3, n3), mag_i16_fix(r2, n2), 0x05040100u);
 }
 
+// [phase:end]
 // ---- probe: how does v_cvt_pk_u8_f32 round here? --------------------------------------------
 __global__ void probe_cvt_kernel(uint32_t *out)
 {
@@ -299,6 +340,7 @@ __device__ __forceinline__ uint32_t pair_at_cold(const uint32_t *ra, const uint3
     }
 }
 
+// [phase:3 decode_candidate]
 // XOR / sum over each row of 16 lanes (a decode group), result in every lane: four DPP steps (VALU
 // latency each) instead of four ds_bpermute round trips through the LDS.
 #define ADSB_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
@@ -399,6 +441,7 @@ __device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *
     return valid;
 }
 
+// [phase:end]
 // Where a tile sits: global tile id -> channel, first sample, number of valid offsets.
 struct TilePos {
     uint32_t ch;
@@ -428,6 +471,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? (int)nrec : 0, 0x00020000);
 }
 
+#ifndef ADSB_PERSIST
+#define ADSB_PERSIST 0 // 1: persistent workgroups drawing tiles from per-XCD ticket counters
+#endif
+// Next tile (relative to tile_first) for a workgroup drawing from XCD `src`'s counter; moves on to the next
+// XCD's counter when one is exhausted; kNoBase when all eight are.  One lane calls this.
+__device__ __forceinline__ uint32_t claim_tile(const DemodArgs &p, uint32_t &src, uint32_t &tries)
+{
+    while (tries < 8u) {
+        const uint32_t rel = src + 8u * atomicAdd(&p.tickets[src * kTicketStride], 1u);
+        if (rel < p.tile_count) return rel;
+        src = (src + 1u) & 7u;
+        ++tries;
+    }
+    return kNoBase;
+}
+
 #ifndef ADSB_ABL_PHASES
 #define ADSB_ABL_PHASES 3 // measurement only (no frames come out below 3): 1 = magnitudes only, 2 = magnitudes + gate
 #endif
@@ -448,6 +507,7 @@ struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 
+// [phase:2 gate: set-up]
 template <int ST, int GROUP, int RUN, int NT, int HOOK_AT = -1, class HOOK = NoHook>
 __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, uint32_t *cand, uint16_t *list,
                                            uint32_t *count, const uint32_t tid, const uint32_t n_valid,
@@ -493,6 +553,7 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
 #pragma unroll
     for (int j = 1; j < 8; ++j) F[j] = pkmax3<ST>(N[j], W3[j + 2], N[j + 5]);
 
+    // [phase:2 gate: steps]
     // GROUP consecutive steps share one wave-uniform test: their 8 x GROUP min/max instructions form one
     // basic block (independent chains the scheduler can interleave) and the common path takes one
     // scalar branch per GROUP steps.  GROUP = 1 is what the many-waves-per-SIMD tile kernel uses; the
@@ -533,6 +594,7 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
             any |= pa[gi] | pb[gi];
 #endif
         }
+        // [phase:2 gate: DF17 (cold)]
         // wave-uniform test (a scalar branch, no exec juggling): the block below is entered by
         // the whole wave when any lane passes; its effects are masked by pa/pb anyway
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
@@ -552,6 +614,7 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
             }
         }
     }
+    // [phase:2 gate: survivor list]
 #if ADSB_ABL_NOCMP
     if (abl_acc == 0x12345678u) atomicOr(candA, 1u);
 #endif
@@ -586,6 +649,7 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
     }
 }
 
+// [phase:end]
 // The same descriptor as four dwords (for inline asm): base, base_hi (stride 0), num_records, flags.
 template <int BPS, int MAG = kMag>
 __device__ __forceinline__ u32x4 tile_rsrc_words(const DemodArgs &p, const TilePos &t, bool live)
@@ -607,6 +671,14 @@ __device__ __forceinline__ u32x4 tile_rsrc_words(const DemodArgs &p, const TileP
 #define ADSB_LOAD_AUX 2
 #endif
 constexpr int kRawIters = (kMag + kThreads * 8 - 1) / (kThreads * 8); // 17 x 16 B per lane (i8)
+#ifndef ADSB_P1_TYPED
+#define ADSB_P1_TYPED 0 // 1: i8 phase 1 through format-converting loads (see tbuffer_load_v4f16)
+#endif
+#ifndef ADSB_TYPED_DEPTH
+#define ADSB_TYPED_DEPTH 32
+#endif
+constexpr int kTypedLoads = (kMag * 2 + kThreads * 4 - 1) / (kThreads * 4); // 65 x 4 B per lane
+constexpr int kTypedDepth = ADSB_TYPED_DEPTH;                               // loads in flight per lane
 
 #ifndef ADSB_WAVES_PER_SIMD
 #define ADSB_WAVES_PER_SIMD (kRun >= 64 ? 4 : (kRun >= 48 ? 5 : 6))
@@ -639,18 +711,74 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     // workgroups: while one waits for its samples the others keep the VALU busy.  (Persistent
     // variants -- atomic tickets, static round-robin, register prefetch of the next tile, single-wave
     // workgroups -- all measured slower)
+#if ADSB_PERSIST
+    // Persistent form: the grid is one workgroup per resident slot (4 per CU) and every workgroup draws tiles
+    // from ticket counters until none is left, so a slot never waits for the dispatcher to launch the next
+    // workgroup (measured per-tile fixed cost of the one-tile-per-workgroup form: ~2 us of ~15).  One counter
+    // per XCD (a single address saturates at ~80 atomics/us, about the rate tiles retire at): XCD x owns tiles
+    // x, x + 8, ...; a workgroup whose own XCD has run dry takes from the next one, so the end of the launch
+    // stays balanced.  The ticket for the NEXT tile is requested right after this tile's loads and read at the
+    // end of the tile: its latency is never exposed.  The last workgroup to leave re-arms the counters.
+    uint32_t src = 0, tries = 0; // (tid 0 only) XCD whose counter is being drawn from; counters found empty
+    if (tid == 0) {
+        src = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u; // HW_REG_XCC_ID[3:0]
+        misc[10] = claim_tile(p, src, tries);
+    }
+    __syncthreads();
+    for (uint32_t tile_rel = misc[10]; tile_rel != kNoBase; tile_rel = misc[10]) {
+        const uint32_t tile = p.tile_first + tile_rel;
+#else
     {
         const uint32_t tile = p.tile_first + blockIdx.x;
+#endif
         const TilePos tp = tile_pos<TC::kTileT>(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
         if (blockIdx.x == 0 && tid == 0) p.hdr->retry = 0;
         if (tid == 0) { misc[8] = 0; misc[12] = 0; } // valid-frame counter, survivor counter
 
+        // [phase:1 magnitude (loads, stores)]
         // ---- phase 1: raw IQ -> magnitudes in LDS ---------------------------------------------
         {
             __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<BPS, TC::kMagT>(p, tp);
-            if (ST == ADSB_SAMPLE_I8) {
+            if (ST == ADSB_SAMPLE_I8 && ADSB_P1_TYPED) {
+                // typed loads: load k covers bytes [1024 k, +1024) of the tile, 4 bytes (2 samples) per lane,
+                // fully coalesced; kTypedDepth of them in flight per lane, re-issued as they are consumed
+                f16x4 q[kTypedLoads];
+                const int voff = (int)tid * 4;
+                const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 2;
+#pragma unroll
+                for (int it = 0; it < kTypedDepth && it < kTypedLoads; ++it)
+                    if ((uint32_t)it * 512 + wave_s0 < (uint32_t)kMag)
+                        q[it] = tbuffer_load_v4f16(rsrc, voff + (it & 3) * 1024, (it & ~3) * 1024, kFmtI8x4ToF16, ADSB_LOAD_AUX);
+#pragma unroll
+                for (int it0 = 0; it0 < kTypedLoads; it0 += 4) {
+                    uint32_t h[8];
+                    float f[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int it = it0 + j < kTypedLoads ? it0 + j : kTypedLoads - 1;
+                        const bool live = (uint32_t)it * 512 + wave_s0 < (uint32_t)kMag; // wave-uniform
+                        const uint2 w = live ? __builtin_bit_cast(uint2, q[it]) : make_uint2(0u, 0u);
+                        h[2 * j] = w.x;
+                        h[2 * j + 1] = w.y;
+                    }
+                    dot2x8_f16(h, f);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int it = it0 + j;
+                        if (it < kTypedLoads) {
+                            const uint32_t s0 = (uint32_t)it * 512 + tid * 2;
+                            const uint32_t m2 = mags2_from_root<MAGMODE>(f[2 * j], f[2 * j + 1]);
+                            if ((uint32_t)it * 512 + wave_s0 < (uint32_t)kMag && s0 < (uint32_t)kMag)
+                                *reinterpret_cast<uint16_t *>(mag + s0) = (uint16_t)m2;
+                            const int nx = it + kTypedDepth;
+                            if (nx < kTypedLoads && (uint32_t)nx * 512 + wave_s0 < (uint32_t)kMag)
+                                q[nx] = tbuffer_load_v4f16(rsrc, voff + (nx & 3) * 1024, (nx & ~3) * 1024, kFmtI8x4ToF16, ADSB_LOAD_AUX);
+                        }
+                    }
+                }
+            } else if (ST == ADSB_SAMPLE_I8) {
                 u32x4 raw[kRawIters];
                 // the last sweep only covers the halo: whole waves past it skip it (scalar branch)
                 const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 8;
@@ -687,17 +815,23 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 }
             }
         }
+#if ADSB_PERSIST
+        uint32_t next_ticket = 0; // requested now, read after phase 3
+        if (tid == 0) next_ticket = atomicAdd(&p.tickets[src * kTicketStride], 1u);
+#endif
         __syncthreads();
 #if ADSB_ABL_PHASES < 2
         // (keeps the LDS stores of phase 1 alive; never true for real data)
         if (mag[tid * 64] == 0xFD && mag[tid * 64 + 1] == 0xFE && n_valid == 7) misc[12] = 1;
 #else
 
+        // [phase:2 gate: call]
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
         gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
 #endif
         __syncthreads();
 
+        // [phase:3 list, slots, records]
         // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
         uint32_t total = misc[12];
 #if ADSB_ABL_PHASES < 3
@@ -805,8 +939,32 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 atomicAdd(&p.grp1[tile >> kGrpShift], e.valid);
                 atomicAdd(&p.grp2[(tile >> (2 * kGrpShift)) * kGrp2Shards + ((tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
             }
+#if ADSB_PERSIST
+            uint32_t rel = src + 8u * next_ticket;
+            if (rel >= p.tile_count) { // this XCD's tiles are gone: take from the others
+                src = (src + 1u) & 7u;
+                ++tries;
+                rel = claim_tile(p, src, tries);
+            }
+            misc[8] = 0;  // valid-frame counter, survivor counter of the next tile
+            misc[12] = 0;
+            misc[10] = rel;
+#endif
+        }
+#if ADSB_PERSIST
+        __syncthreads(); // every wave is done with this tile's LDS; misc[10] is the next tile
+#endif
+    }
+#if ADSB_PERSIST
+    if (tid == 0) { // the last workgroup to leave re-arms the counters for the next launch
+        const uint32_t left = atomicAdd(&p.tickets[8 * kTicketStride], 1u);
+        if (left == gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x <= 8; ++x) __hip_atomic_store(&p.tickets[x * kTicketStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#endif
+    // [phase:end]
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
@@ -816,6 +974,9 @@ template <int ST>
 static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &a, uint32_t grid_x,
                                   hipEvent_t e0, hipEvent_t e1)
 {
+#if ADSB_PERSIST
+    if (a.persist_grid && grid_x > a.persist_grid) grid_x = a.persist_grid;
+#endif
     dim3 grid(grid_x), block(kThreads);
     switch (mag_mode) {
     case 0: hipExtLaunchKernelGGL((demod_tiles<ST, 0>), grid, block, 0, s, e0, e1, 0, a); break;
