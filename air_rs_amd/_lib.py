@@ -19,6 +19,7 @@ ADSB_E_NOMEM = -4
 ADSB_E_NODEVICE = -5
 ADSB_E_STATE = -6
 ADSB_FLAG_TRUNCATED = 0x1
+ADSB_FLAG_INCOMPLETE = 0x2
 ADSB_SAMPLE_I8 = 0
 ADSB_SAMPLE_I16 = 1
 ADSB_MSG_AIRCRAFT_ID, ADSB_MSG_AIRCRAFT_POSITION, ADSB_MSG_UNKNOWN = 0, 1, 2
@@ -106,8 +107,10 @@ PROTOTYPES = {
     "adsb_tracker_count": (C.c_size_t, [C.c_void_p]),
     "adsb_tracker_get": (C.c_int, [C.c_void_p, C.c_uint32, _P(AdsbAircraftSummary)]),
     "adsb_stream": (C.c_void_p, [C.c_void_p]),
+    "adsb_sample_type": (C.c_int, [C.c_void_p]),
     "adsb_stream_wait_results": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adsb_set_result_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_set_stream_base": (C.c_int, [C.c_void_p, C.c_uint64]),
     "adsb_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "adsb_timing_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_uint32)]),
     "adsb_time_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, _P(C.c_double)]),

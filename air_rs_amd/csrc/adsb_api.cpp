@@ -18,10 +18,6 @@
 using adsbk::kTile;
 using adsbk::kWindow;
 
-#ifndef ADSB_DEFAULT_STREAM
-#define ADSB_DEFAULT_STREAM 0
-#endif
-
 namespace {
 constexpr int kTimingRing = 512;
 }
@@ -63,6 +59,8 @@ struct adsb_ctx {
     size_t ext_frames = 0;          // frame capacity of ext_blob
     adsb_frame *last_out = nullptr; // where the last launch's ordered list went
     uint32_t last_cap = 0;
+    uint64_t stream_base = 0;       // adsb_set_stream_base: added to the offsets of the following launches
+    uint64_t last_base = 0;         // ... of the last launch (re-runs of its tiles use the same)
     uint32_t launch_idx = 0;        // launches so far
     uint32_t last = 0;              // result set of the last launch
     uint32_t *out_start = nullptr;  // [n_tiles_max + 1]  (slot-overflow re-run path only)
@@ -177,14 +175,13 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     if (!c) return ADSB_E_NOMEM;
     c->cfg = *cfg;
     c->bps = cfg->sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
-    // Two tile kernels exist for i8 input: one workgroup per tile (demod_tiles, also used for i16) and
-    // the streaming kernel (one persistent workgroup per CU, table-lookup magnitudes).  ADSB_KERNEL =
-    // "tiles" | "stream" picks one at adsb_create; the default is the faster one as measured on MI355X
-    // (DESIGN.md section 5).
+    // The product has ONE i8 kernel, demod_tiles (also used for i16).  Experimental builds (tools/build_variant.sh
+    // stream -DADSB_WITH_STREAM_KERNEL=1 -Itools/experimental) also carry the streaming kernel of DESIGN.md
+    // section 4.3, selected with ADSB_KERNEL=stream at adsb_create; asking for it in a build without it is an error.
     const char *kern = getenv("ADSB_KERNEL");
-    const bool stream_default = ADSB_DEFAULT_STREAM != 0;
-    const bool want_stream = cfg->sample_type == ADSB_SAMPLE_I8 &&
-                 (kern ? strcmp(kern, "stream") == 0 : stream_default);
+    const bool ask_stream = kern && strcmp(kern, "stream") == 0;
+    if (ask_stream && !adsbk::stream_kernel_built()) { delete c; return ADSB_E_ARG; }
+    const bool want_stream = cfg->sample_type == ADSB_SAMPLE_I8 && ask_stream;
     uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type, want_stream) * cfg->max_channels;
     if (tiles == 0) tiles = 1;
     if (tiles * adsbk::kQuota + cfg->max_out + kTile > 0xFFFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
@@ -255,6 +252,8 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
                 fail(ADSB_E_NODEVICE);
                 break;
             }
+            // cycle counters of diagnostic builds (-DADSB_TILE_STAMPS=1, -DADSB_STAMPS=1); zeros otherwise
+            if (hipMalloc((void **)&c->stamps, 512) != hipSuccess || hipMemsetAsync(c->stamps, 0, 512, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
             const size_t tb = sizeof(uint32_t) * 9 * adsbk::kTicketStride;
             if (hipMalloc((void **)&c->tickets, tb) != hipSuccess || hipMemsetAsync(c->tickets, 0, tb, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
             c->persist_grid = (uint32_t)n_cu * 4u;
@@ -266,8 +265,7 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
                 fail(ADSB_E_NODEVICE);
                 break;
             }
-            if (hipMalloc((void **)&c->lut, 65536) != hipSuccess || hipMalloc((void **)&c->stamps, 512) != hipSuccess ||
-                hipMemsetAsync(c->stamps, 0, 512, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
+            if (hipMalloc((void **)&c->lut, 65536) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
             e = adsbk::launch_build_lut(c->stream, c->lut);
             if (e != hipSuccess) { fail((int)e); break; }
             c->stream_grid = (uint32_t)n_cu;
@@ -280,6 +278,7 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
 }
 
 extern "C" void *adsb_stream(adsb_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int adsb_sample_type(const adsb_ctx *c) { return c ? c->cfg.sample_type : ADSB_E_ARG; }
 extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
 extern "C" int adsb_debug_kernel(adsb_ctx *c) { return c ? (c->stream_grid ? 1 : 0) : ADSB_E_ARG; }
 
@@ -327,11 +326,13 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.tile_first = tile_first;
     a.tile_count = tile_count;
     a.count_groups = count_groups ? 1u : 0u;
+    a.offset_base = c->last_base;
     a.seg = r.seg;
     a.slots = r.slots;
     a.pool_first = c->n_tiles_max * adsbk::kQuota;
     a.cap_slots = c->cap_slots;
     a.hdr = r.hdr;
+    a.hdr_pub = (count_groups && c->ext_blob) ? static_cast<uint64_t *>(c->ext_blob) : nullptr;
     a.grp1 = grp1_of(c, grp_set);
     a.grp2 = grp2_of(c, grp_set);
     a.lut = c->lut;
@@ -388,6 +389,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_stride = channel_stride;
     c->last_tpc = tiles_for(n_samples, c->cfg.sample_type, c->stream_grid != 0);
     c->last_tiles = c->last_tpc * n_channels;
+    c->last_base = c->stream_base;
     c->launched = true;
     c->fields_current = false;
     c->trk_done = false;
@@ -469,6 +471,13 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
     }
     HIPCHK(hipMemsetAsync(&r.hdr->alloc, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(&r.hdr->retry, 0, sizeof(uint32_t), c->stream));
+    if (rc == ADSB_OK) { // the list is whole now: drop ADSB_FLAG_INCOMPLETE where device-side consumers read it
+        c->hdr_host->flags &= ~ADSB_FLAG_INCOMPLETE;
+        const uint64_t pub_flags = c->hdr_host->flags;
+        HIPCHK(hipMemcpyAsync(&r.hdr->flags, &c->hdr_host->flags, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (c->last_out != r.out) // the launch wrote into a caller-owned blob: [n_out | total | flags | 0 | frames]
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(c->last_out) - 16, &pub_flags, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return rc;
 }
@@ -642,6 +651,13 @@ extern "C" int adsb_set_result_target(adsb_ctx *c, void *blob_dev, size_t blob_b
     if (((uintptr_t)blob_dev & 15u) || blob_bytes < 32 + sizeof(adsb_frame)) return ADSB_E_ARG;
     c->ext_blob = blob_dev;
     c->ext_frames = (blob_bytes - 32) / sizeof(adsb_frame);
+    return ADSB_OK;
+}
+
+extern "C" int adsb_set_stream_base(adsb_ctx *c, uint64_t first_sample_index)
+{
+    if (!c) return ADSB_E_ARG;
+    c->stream_base = first_sample_index;
     return ADSB_OK;
 }
 

@@ -78,11 +78,13 @@ struct DemodArgs {
     uint32_t tile_first;       // global tile id of blockIdx.x == 0
     uint32_t tile_count;       // workgroups in this launch
     uint32_t count_groups;     // 1: add Seg::valid into grp1/grp2; 0: re-run of known tiles
+    uint64_t offset_base;      // added to every frame's offset (adsb_set_stream_base: position of sample 0 in a longer stream)
     Seg *seg;
     adsb_frame *slots;         // [n_tiles_max * kQuota] fixed region, then the pool
     uint32_t pool_first;       // index of the pool's first slot
     uint32_t cap_slots;        // pool capacity
     Header *hdr;
+    uint64_t *hdr_pub;         // optional caller-owned header copy (adsb_set_result_target): its flags word is cleared here
     uint32_t *grp1, *grp2;     // this launch's parity
     // streaming kernel (i8 only): the 64 KB floor(sqrt(I^2+Q^2)) table and the persistent grid size
     // (number of CUs); stream_grid == 0 selects the one-workgroup-per-tile kernel
@@ -123,8 +125,10 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const Demo
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nullptr,
                          hipEvent_t e1 = nullptr);
 
-// 64 KB magnitude table of the streaming kernel (built once per context)
+// 64 KB magnitude table of the experimental streaming kernel (built once per context); that kernel is only
+// present in -DADSB_WITH_STREAM_KERNEL=1 builds (tools/experimental/)
 hipError_t launch_build_lut(hipStream_t s, uint8_t *lut_dev);
+bool stream_kernel_built();
 
 // field decode of an ordered frame list (count read from hdr->n_out on the device)
 hipError_t launch_decode_fields(hipStream_t s, const adsb_frame *frames, const Header *hdr, uint32_t cap,

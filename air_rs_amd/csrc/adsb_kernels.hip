@@ -471,6 +471,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? (int)nrec : 0, 0x00020000);
 }
 
+// Diagnostic build (-DADSB_TILE_STAMPS=1; measurement only): lane 0 of waves 0 and 3 of every workgroup add the
+// shader cycles (s_memtime) they spent in each segment of a tile to DemodArgs::stamps (8 words per wave: prologue
+// up to the loads issued, phase 1 incl. the wait for the loads, barrier, phase 2, barrier, phase 3, -, tiles).
+#ifndef ADSB_TILE_STAMPS
+#define ADSB_TILE_STAMPS 0
+#endif
+#if ADSB_TILE_STAMPS
+#define TSTAMP(k)                                                                                              \
+    do {                                                                                                       \
+        if ((tid & 63u) == 0 && (wave == 0 || wave == 3)) {                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                      \
+            if ((k) >= 0) atomicAdd(&p.stamps[(wave ? 8 : 0) + (k)], now_ - ts_prev);                          \
+            ts_prev = now_;                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }                                                                                                      \
+    } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+
 #ifndef ADSB_PERSIST
 #define ADSB_PERSIST 0 // 1: persistent workgroups drawing tiles from per-XCD ticket counters
 #endif
@@ -704,6 +725,10 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     const uint32_t lane = tid & 63, wave = tid >> 6;
 
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
+#if ADSB_TILE_STAMPS
+    unsigned long long ts_prev = 0;
+    TSTAMP(-1);
+#endif
 
     if (tid < 112) syn[tid] = kSyn.v[tid];
     // One tile per workgroup; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU
@@ -734,7 +759,13 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         const TilePos tp = tile_pos<TC::kTileT>(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
-        if (blockIdx.x == 0 && tid == 0) p.hdr->retry = 0;
+        if (blockIdx.x == 0 && tid == 0) {
+            p.hdr->retry = 0;
+            if (p.count_groups) { // first pass of a launch: the ordering pass ORs this launch's flags in
+                p.hdr->flags = 0;
+                if (p.hdr_pub) p.hdr_pub[2] = 0;
+            }
+        }
         if (tid == 0) { misc[8] = 0; misc[12] = 0; } // valid-frame counter, survivor counter
 
         // [phase:1 magnitude (loads, stores)]
@@ -786,6 +817,11 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 for (int it = 0; it < kRawIters; ++it)
                     if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag)
                         raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
+                TSTAMP(0); // prologue, loads issued
+#if ADSB_TILE_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
+                TSTAMP(6);                                       // ... as its own segment
+#endif
 #pragma unroll
                 for (int it = 0; it < kRawIters; ++it) {
                     if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag) {
@@ -819,7 +855,9 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         uint32_t next_ticket = 0; // requested now, read after phase 3
         if (tid == 0) next_ticket = atomicAdd(&p.tickets[src * kTicketStride], 1u);
 #endif
+        TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
+        TSTAMP(2); // barrier
 #if ADSB_ABL_PHASES < 2
         // (keeps the LDS stores of phase 1 alive; never true for real data)
         if (mag[tid * 64] == 0xFD && mag[tid * 64 + 1] == 0xFE && n_valid == 7) misc[12] = 1;
@@ -829,7 +867,9 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
         gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
 #endif
+        TSTAMP(3); // phase 2
         __syncthreads();
+        TSTAMP(4); // barrier
 
         // [phase:3 list, slots, records]
         // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
@@ -918,7 +958,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                     slot = row16_sum(below);
                 }
                 unsigned char *rec = res + g * 24;
-                const bool valid = decode_candidate<ST>(mag, syn, rec, have, off, sample0, l, lane);
+                const bool valid = decode_candidate<ST>(mag, syn, rec, have, off, sample0 + p.offset_base, l, lane);
                 if (valid && l == 0) atomicAdd(&misc[8], 1u);
                 if (have && base_slot != kNoBase && l < 6) {
                     uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + slot);
@@ -927,6 +967,11 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
             }
             __syncthreads();
         }
+        TSTAMP(5); // phase 3
+#if ADSB_TILE_STAMPS
+        if (tid == 0) atomicAdd(&p.stamps[7], 1ull);
+        if (tid == 192) atomicAdd(&p.stamps[15], 1ull);
+#endif
         // (total == 0: nothing was added to misc[8] since tid 0 cleared it before the phase-1 barrier)
         if (tid == 0) {
             Seg e;
@@ -986,13 +1031,27 @@ static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &
     return hipGetLastError();
 }
 
+// The streaming form of the i8 kernel (one persistent 1024-thread workgroup per CU, table-lookup magnitudes) is an
+// experiment that never beat demod_tiles at the bench size.  It lives in
+// tools/experimental/ and is compiled in only by `tools/build_variant.sh stream -DADSB_WITH_STREAM_KERNEL=1
+// -Itools/experimental`; the product build has one i8 kernel.
+#ifndef ADSB_WITH_STREAM_KERNEL
+#define ADSB_WITH_STREAM_KERNEL 0
+#endif
+#if ADSB_WITH_STREAM_KERNEL
 #include "adsb_stream_kernel.h"
+#else
+hipError_t launch_build_lut(hipStream_t, uint8_t *) { return hipErrorNotSupported; }
+#endif
+bool stream_kernel_built() { return ADSB_WITH_STREAM_KERNEL != 0; }
 
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (a.tile_count == 0) return hipSuccess;
+#if ADSB_WITH_STREAM_KERNEL
     if (sample_type == ADSB_SAMPLE_I8 && a.lut && a.stream_grid) return launch_demod_stream(s, a, a.stream_grid, e0, e1);
+#endif
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);
     return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count, e0, e1);
 }
@@ -1043,12 +1102,13 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
         if (lane == 0) {
             a.hdr->total_found = total;
             a.hdr->n_out = total < a.max_out ? total : a.max_out;
-            a.hdr->flags = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
+            // flags were cleared by the demod kernel; bits are OR-ed in (another wave may add INCOMPLETE below)
+            if (total > a.max_out) atomicOr(&a.hdr->flags, ADSB_FLAG_TRUNCATED);
             a.hdr->alloc = 0;     // ready for the next launch
             if (a.hdr_pub) {
                 a.hdr_pub[0] = total < a.max_out ? total : a.max_out;
                 a.hdr_pub[1] = total;
-                a.hdr_pub[2] = total > a.max_out ? ADSB_FLAG_TRUNCATED : 0u;
+                if (total > a.max_out) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_TRUNCATED);
                 a.hdr_pub[3] = 0;
             }
         }
@@ -1079,7 +1139,12 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
             run += valid[k];
             if (valid[k] == 0 || pos[k] >= a.max_out) cand[k] = 0; // nothing of this tile is wanted
             if (cand[k] && base[k] == kNoBase) { // its slots were dropped but its frames are wanted: host re-plans
-                if (lane == 0) atomicOr(&a.hdr->retry, 1u);
+                if (lane == 0) {
+                    atomicOr(&a.hdr->retry, 1u);
+                    // visible to device-side consumers too: the list has holes until the host has re-planned
+                    atomicOr(&a.hdr->flags, ADSB_FLAG_INCOMPLETE);
+                    if (a.hdr_pub) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_INCOMPLETE);
+                }
                 cand[k] = 0;
             }
             maxcand = cand[k] > maxcand ? cand[k] : maxcand;

@@ -110,6 +110,9 @@ static int pipeline(adsb_ctx *ctx, int sample_type, const void *data, size_t n_s
                     size_t text_cap, size_t *text_len, bool carry_over)
 {
     if (!ctx || !data || chunk_len == 0) return ADSB_E_ARG;
+    // the context copies n * (its own bytes per sample) out of every chunk: the caller's idea of the sample
+    // type must be the context's, or host memory is over-read (i8 data, i16 context) or decoded as garbage
+    if (sample_type != adsb_sample_type(ctx)) return ADSB_E_ARG;
     if (sample_type == ADSB_SAMPLE_I16)
         return run_pipeline<int16_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
                                      text, text_cap, text_len, carry_over);

@@ -116,6 +116,7 @@ class AdsbDemod:
         self.sample_type = sample_type
         self.max_out = max_out
         self.max_channels = max_channels
+        self._last_channels = 1   # channels of the last launch (adsb_demod is single-channel)
         self._np_dtype = np.int8 if sample_type == L.ADSB_SAMPLE_I8 else np.int16
 
     def close(self):
@@ -149,7 +150,9 @@ class AdsbDemod:
 
     @property
     def kernel(self):
-        """'stream' (i8 default) or 'tiles' (i16; i8 with ADSB_KERNEL=tiles at creation)."""
+        """'tiles' (demod_tiles: the product's only kernel) or 'stream' (the experimental streaming kernel of
+        tools/experimental/, present only in -DADSB_WITH_STREAM_KERNEL=1 builds and then chosen with
+        ADSB_KERNEL=stream at creation)."""
         return "stream" if self._lib.adsb_debug_kernel(self._h) == 1 else "tiles"
 
     # -- behind the channel: tracker + CPR on the device (aircraft.rs, cpr.rs) ------------------------
@@ -194,6 +197,7 @@ class AdsbDemod:
         L.check(self._lib.adsb_demod(self._h, iq.ctypes.data, n,
                                      out.ctypes.data_as(C.POINTER(L.AdsbFrame)), cap, C.byref(n_out),
                                      C.byref(flags)), "adsb_demod")
+        self._last_channels = 1
         return out[:n_out.value].copy(), flags.value
 
     # -- HBM-resident, asynchronous -----------------------------------------------------------------
@@ -201,18 +205,23 @@ class AdsbDemod:
         stride = n_samples if channel_stride is None else channel_stride
         L.check(self._lib.adsb_demod_device_async(self._h, dev_ptr, n_channels, n_samples, stride),
                 "adsb_demod_device_async")
+        self._last_channels = int(n_channels)
 
-    def fetch(self, max_out=None, n_channels=1):
+    def fetch(self, max_out=None, n_channels=None):
+        """Frames of the last launch: (frames, per-channel counts, total_found, flags).  adsb_fetch writes one
+        count per channel of the LAST LAUNCH, so the array handed to it always holds max_channels entries; the
+        first `n_channels` (default: the last launch's) are returned."""
         cap = self.max_out if max_out is None else max_out
         out = np.zeros(max(cap, 1), dtype=FRAME_DTYPE)
         n_out = C.c_size_t()
         total = C.c_uint64()
         flags = C.c_uint32()
-        counts = (C.c_uint64 * n_channels)()
+        counts = (C.c_uint64 * max(self.max_channels, 1))()
         L.check(self._lib.adsb_fetch(self._h, out.ctypes.data_as(C.POINTER(L.AdsbFrame)), cap,
                                      C.byref(n_out), counts, C.byref(total), C.byref(flags)),
                 "adsb_fetch")
-        return out[:n_out.value].copy(), list(counts), total.value, flags.value
+        n = self._last_channels if n_channels is None else min(int(n_channels), self.max_channels)
+        return out[:n_out.value].copy(), list(counts)[:n], total.value, flags.value
 
     def fetch_counts(self):
         n_out, total, flags = C.c_uint64(), C.c_uint64(), C.c_uint32()
@@ -238,6 +247,10 @@ class AdsbDemod:
     def set_result_target(self, dev_ptr, nbytes):
         """Next launches write [32-byte header | frames] straight into caller-owned HBM (None: reset)."""
         L.check(self._lib.adsb_set_result_target(self._h, dev_ptr, nbytes), "adsb_set_result_target")
+
+    def set_stream_base(self, first_sample_index):
+        """Frames of the following launches carry offset = first_sample_index + index inside the buffer."""
+        L.check(self._lib.adsb_set_stream_base(self._h, int(first_sample_index)), "adsb_set_stream_base")
 
     def stream_wait_results(self, stream):
         """Make `stream` (hipStream_t as int) wait for the last launch's ordered frame list."""

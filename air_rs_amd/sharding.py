@@ -78,3 +78,166 @@ def gather_frame_lists(local_frames: np.ndarray, first_offset: int, dist, device
     # concatenation in rank order is already sorted because shards are disjoint and ascending
     assert (np.diff(merged["offset"].astype(np.int64)) > 0).all() if len(merged) > 1 else True
     return merged
+
+
+# ---- per-launch frame lists to rank 0, one collective per BUCKET launches ---------------------------------
+# Payload of one launch = what adsb_set_result_target() makes the ordering pass write (include/adsb_hip.h):
+#   [ u64 n_out | u64 total_found | u64 flags | u64 0 | adsb_frame[cap] ]   (16-byte aligned)
+HEADER_BYTES = 32
+FRAME_BYTES = FRAME_DTYPE.itemsize  # 24
+
+
+def payload_bytes(cap_frames: int) -> int:
+    return (HEADER_BYTES + int(cap_frames) * FRAME_BYTES + 15) // 16 * 16
+
+
+def write_payload(slot, frames: np.ndarray, total_found=None, flags: int = 0):
+    """Fill one payload slot (a uint8 torch tensor on the CPU) the way the HIP ordering pass fills it on the
+    device.  Used by CPU-tier tests, whose per-rank demodulator is a stand-in for the HIP path."""
+    cap = (slot.numel() - HEADER_BYTES) // FRAME_BYTES
+    n = min(len(frames), cap)
+    total = len(frames) if total_found is None else int(total_found)
+    raw = slot.numpy()
+    raw[:HEADER_BYTES].view(np.uint64)[:] = (n, total, flags | (1 if total > n else 0), 0)
+    raw[HEADER_BYTES:HEADER_BYTES + n * FRAME_BYTES] = np.ascontiguousarray(frames[:n]).view(np.uint8)
+
+
+def parse_payload(raw: np.ndarray):
+    """(n_out, total_found, flags, frames) of one payload given as a uint8 numpy array."""
+    n_out, total, flags, _ = (int(x) for x in raw[:HEADER_BYTES].view(np.uint64))
+    frames = raw[HEADER_BYTES:HEADER_BYTES + n_out * FRAME_BYTES].view(FRAME_DTYPE)
+    return n_out, total, flags, frames
+
+
+class BucketGather:
+    """Moves every rank's per-launch frame lists to rank 0 with ONE torch.distributed gather per `bucket`
+    launches (backend `nccl` = RCCL over xGMI on the GPUs, `gloo` on the CPU for tests; the code is the same).
+
+    A cross-stream hand-off per launch costs 40-60 us on MI355X (15-20 % of a 1 GiB step),
+    so launches write their ordered list straight into slot i % bucket of a bucket (zero copies:
+    adsb_set_result_target), a full bucket is gathered from a side stream while the next bucket fills, and two
+    buckets alternate.  Offsets are absolute (adsb_set_stream_base), so rank 0 concatenates the lists of one
+    launch in rank order and has the globally ordered list.
+
+    Use, per launch:   ptr = bg.begin_launch()         # slot to write; waits (stream-side) for the gather
+                       ...enqueue the launch...        #   that still reads this half of the double buffer
+                       bg.end_launch(wait_results)     # full bucket -> gather
+    then once:         bg.drain()
+    Rank 0 reads the gathered lists with lists_of_launch(); with keep=True every launch's lists are parsed as
+    the buckets complete (tests), otherwise only the last two buckets are available (bench.py: no host work
+    inside the timed region).
+    """
+
+    def __init__(self, dist, cap_frames: int, bucket: int = 8, device="cpu", keep: bool = False, dst: int = 0):
+        import torch
+        self.torch = torch
+        self.dist, self.rank, self.world, self.dst = dist, dist.get_rank(), dist.get_world_size(), dst
+        self.bucket, self.payload, self.keep = int(bucket), payload_bytes(cap_frames), keep
+        self.cuda = str(device).startswith("cuda")
+        size = self.bucket * self.payload
+        self.buf = [torch.zeros(size, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [[torch.empty(size, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                     if self.rank == dst else None for _ in range(2)]
+        self.side = torch.cuda.Stream() if self.cuda else None
+        self.pending = [None, None]       # outstanding gather per half
+        self.filled = [0, 0]              # launches in the gather outstanding / last completed per half
+        self.first = [0, 0]               # index of the first launch of that bucket
+        self.i = 0                        # launches begun
+        self.open = False                 # a launch has begun and not ended
+        self.kept = {}                    # keep=True, rank dst: launch index -> [per-rank (n_out, total, flags, frames)]
+
+    # -- per launch ------------------------------------------------------------------------------------
+    def _half_slot(self, i):
+        return (i // self.bucket) & 1, i % self.bucket
+
+    def begin_launch(self):
+        """Returns (data_ptr, uint8 tensor view) of the payload slot the next launch must fill."""
+        assert not self.open
+        bk, slot = self._half_slot(self.i)
+        if slot == 0:
+            self._retire(bk)              # the gather that still reads this half (two buckets ago)
+            self.first[bk] = self.i
+        view = self.buf[bk][slot * self.payload:(slot + 1) * self.payload]
+        self.open = True
+        return view.data_ptr(), view
+
+    def end_launch(self, wait_results=None):
+        """The launch that fills the slot handed out by begin_launch() has been enqueued (or, on the CPU, has
+        written it).  wait_results(stream_handle) must make that stream wait for the launch's results
+        (AdsbDemod.stream_wait_results); it is called only when a bucket is flushed."""
+        assert self.open
+        self.open = False
+        bk, slot = self._half_slot(self.i)
+        self.i += 1
+        if slot == self.bucket - 1:
+            self._flush(bk, self.bucket, wait_results)
+
+    def _flush(self, bk, n_launches, wait_results):
+        torch = self.torch
+        self.filled[bk] = n_launches
+        if self.cuda:
+            if wait_results is not None:
+                wait_results(self.side.cuda_stream)   # side stream waits for the last ordering pass
+            with torch.cuda.stream(self.side):
+                self.pending[bk] = self.dist.gather(self.buf[bk], self.recv[bk], dst=self.dst, async_op=True)
+        else:
+            self.pending[bk] = self.dist.gather(self.buf[bk], self.recv[bk], dst=self.dst, async_op=True)
+
+    def _retire(self, bk):
+        if self.pending[bk] is not None:
+            self.pending[bk].wait()       # (CUDA: the current stream waits; the host does not block)
+            self.pending[bk] = None
+            if self.keep and self.rank == self.dst:
+                if self.cuda:
+                    self.torch.cuda.current_stream().synchronize()
+                for k in range(self.filled[bk]):
+                    self.kept[self.first[bk] + k] = self._parse(bk, k)
+
+    def drain(self, wait_results=None):
+        """Flush a partly filled bucket and wait for every outstanding gather."""
+        assert not self.open
+        bk, slot = self._half_slot(self.i)
+        if slot != 0:                      # partial bucket: slots >= slot hold older launches and are ignored
+            self._flush(bk, slot, wait_results)
+            self.i += self.bucket - slot   # the next launch starts a fresh bucket
+        for h in ((bk + 1) & 1, bk):       # oldest first
+            if self.pending[h] is not None:
+                self.pending[h].wait()
+                if self.side is not None:
+                    self.side.synchronize()
+                self.pending[h] = None
+                if self.keep and self.rank == self.dst:
+                    for k in range(self.filled[h]):
+                        self.kept[self.first[h] + k] = self._parse(h, k)
+
+    # -- rank dst: what arrived --------------------------------------------------------------------------
+    def _parse(self, bk, slot):
+        out = []
+        for r in range(self.world):
+            raw = self.recv[bk][r][slot * self.payload:(slot + 1) * self.payload].cpu().numpy().copy()
+            out.append(parse_payload(raw))
+        return out
+
+    def lists_of_launch(self, launch: int):
+        """Rank dst, after drain(): [(n_out, total_found, flags, frames)] per rank for launch index `launch`
+        (any launch with keep=True; otherwise only launches of the two most recent buckets)."""
+        assert self.rank == self.dst
+        if launch in self.kept:
+            return self.kept[launch]
+        for bk in (0, 1):
+            if self.first[bk] <= launch < self.first[bk] + self.filled[bk]:
+                return self._parse(bk, launch - self.first[bk])
+        raise KeyError(f"launch {launch} is no longer held (keep=False keeps two buckets)")
+
+    def last_launch(self):
+        bk = max((0, 1), key=lambda h: self.first[h] + self.filled[h] if self.filled[h] else -1)
+        return self.first[bk] + self.filled[bk] - 1
+
+
+def merge_rank_lists(per_rank):
+    """Concatenate one launch's per-rank lists (absolute offsets) in rank order; asserts global order."""
+    parts = [f for (_, _, _, f) in per_rank]
+    merged = np.concatenate(parts) if parts else np.zeros(0, dtype=FRAME_DTYPE)
+    if len(merged) > 1:
+        assert (np.diff(merged["offset"].astype(np.int64)) > 0).all(), "per-rank lists are not globally ordered"
+    return merged

@@ -42,6 +42,13 @@ extern "C" {
 /* More than max_out frames exist; the first max_out (in offset order) were returned.
  * The reference has no cap (unbounded mpsc); see SURVEY F8 for why a cap is needed. */
 #define ADSB_FLAG_TRUNCATED 0x1u
+/* Only ever seen by device-side consumers (adsb_result_device's header, adsb_set_result_target's blob):
+ * the launch ran out of temporary frame slots (far more gate survivors than max_out + one tile: constant or
+ * all-zero input), so the list holds n_out entries of which some are not written yet.  The host
+ * entry points that wait for a launch (adsb_fetch, adsb_fetch_counts, adsb_fetch_fields, adsb_track_device)
+ * re-run the affected tiles, complete the list IN PLACE (blob included) and clear the flag; a consumer
+ * that reads the device copy directly must check it and call adsb_fetch_counts() first when it is set. */
+#define ADSB_FLAG_INCOMPLETE 0x2u
 
 /* ---- sample formats ---------------------------------------------------------------------- */
 /* ADSB_SAMPLE_I16 is the reference's `Complex<i16>` memory layout: interleaved {re, im},
@@ -125,6 +132,8 @@ int adsb_fetch_counts(adsb_ctx *ctx, uint64_t *n_out, uint64_t *total_found, uin
  *   frames_dev : adsb_frame[ ] in device memory
  *   header_dev : device pointer to { uint64 n_out; uint64 total_found; uint32 flags; ... }
  * Order a consumer stream behind the launch that fills them with adsb_stream_wait_results().
+ * If header.flags has ADSB_FLAG_INCOMPLETE the list has holes: call adsb_fetch_counts() (it re-runs what
+ * is missing and clears the flag) before using it.
  * A context alternates between two result sets, so these pointers stay valid (and unchanged) until
  * the second-next adsb_demod_device_async() on this context.
  */
@@ -137,7 +146,16 @@ int adsb_result_device(adsb_ctx *ctx, const adsb_frame **frames_dev, const void 
  * no device-to-device copy.  blob_dev == NULL returns to the context's own buffers.
  */
 int adsb_set_result_target(adsb_ctx *ctx, void *blob_dev, size_t blob_bytes);
-/* Makes `stream` (hipStream_t) wait for the results of the last launch; does not block the host. */
+/*
+ * Position of the next launches' sample 0 inside a longer stream: every frame of the following launches is
+ * reported with offset = first_sample_index + (index of its first preamble sample inside the buffer), in
+ * every channel.  0 (the default) gives the reference's per-buffer offsets (adsb.rs:98).  A rank that owns
+ * the slice [first, first + n) of a time-sharded stream sets this to `first`, and the per-rank lists
+ * concatenate into one globally ordered list with no host-side rebasing.
+ */
+int adsb_set_stream_base(adsb_ctx *ctx, uint64_t first_sample_index);
+/* Makes `stream` (hipStream_t) wait for the results of the last launch; does not block the host.
+ * (It cannot repair an ADSB_FLAG_INCOMPLETE list: that takes the host, see adsb_fetch_counts.) */
 int adsb_stream_wait_results(adsb_ctx *ctx, void *stream);
 
 /*
@@ -203,6 +221,8 @@ int adsb_fetch_track(adsb_ctx *ctx, adsb_track_point *points, size_t max_points,
 
 /* The stream the ctx enqueues on (hipStream_t as void*). */
 void *adsb_stream(adsb_ctx *ctx);
+/* cfg.sample_type the ctx was created with (ADSB_SAMPLE_*); ADSB_E_ARG for NULL. */
+int adsb_sample_type(const adsb_ctx *ctx);
 
 /* ---- measurement / test helpers (bench.py, tests; not part of the reference's surface) ----- */
 /*
@@ -224,13 +244,15 @@ int adsb_debug_magnitudes(adsb_ctx *ctx, const void *iq_host, size_t n_samples,
 /* How v_cvt_pk_u8_f32 was found to round on this device: 0 truncates, 1 truncates under
  * MODE.fp_round = toward-zero, 2 rounds to nearest (kernel subtracts 0.5 first). */
 int adsb_debug_mag_mode(adsb_ctx *ctx);
-/* Which tile kernel the context launches: 1 = streaming kernel (i8 default: one persistent workgroup per
- * CU, magnitudes by table lookup), 0 = one workgroup per tile (i16; i8 when ADSB_KERNEL=tiles was set
- * in the environment at adsb_create). */
+/* Which kernel the context launches: 0 = demod_tiles, one workgroup per tile -- the only kernel of the product
+ * build, for i8 and i16 alike.  1 = the experimental streaming kernel (one persistent workgroup per CU,
+ * magnitudes by table lookup), which exists only in libraries built with -DADSB_WITH_STREAM_KERNEL=1
+ * (tools/experimental/) and is then selected by ADSB_KERNEL=stream in the environment at adsb_create; in the
+ * product build that setting makes adsb_create fail with ADSB_E_ARG. */
 int adsb_debug_kernel(adsb_ctx *ctx);
-/* The streaming kernel's 64 KB magnitude table as it sits on the device: entry
+/* Experimental streaming kernel only: its 64 KB magnitude table as it sits on the device: entry
  * r ^ ((r >> 6) & 0x3FC) holds floor(sqrt(I^2+Q^2)) of the raw sample r = (Q << 8) | I (utils.rs:46-52).
- * ADSB_E_STATE if the context does not use the streaming kernel. */
+ * ADSB_E_STATE if the context does not use the streaming kernel (always, in the product build). */
 int adsb_debug_lut(adsb_ctx *ctx, uint8_t *table_host65536);
 /* Diagnostic builds of the streaming kernel (-DADSB_STAMPS=1) only: per-segment shader-cycle sums of
  * workgroup 0 over the last launch (zeros in a normal build). */

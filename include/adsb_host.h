@@ -50,7 +50,7 @@ size_t adsb_packet_display(const uint8_t bytes[14], const char *time_text, char 
  * launch_adsb in playback + stream mode (adsb.rs:126-173): thread 1 = playback_thread over
  * `data`, thread 2 = process_sdr_data_thread on `ctx` (GPU), thread 3 collects what the stream
  * printer would print ("\n{packet}\n" per packet, adsb.rs:157).
- *   sample_type : layout of `data` (must match the ctx)
+ *   sample_type : layout of `data`; ADSB_E_ARG unless it is the sample type the ctx was created with
  *   chunk_len   : samples per buffer (20000 in the reference); the tail is dropped as in adsb.rs:77
  *   frames/max_frames/n_frames : the frames behind the packets, offsets absolute in `data`
  *   text/text_cap/text_len     : optional stream-mode text, "Processed Time" lines blanked

@@ -10,11 +10,17 @@ import air_rs_amd as A
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["stream", "tiles"], autouse=True)
+def _kernel_kinds():
+    # The product build has one kernel (demod_tiles).  A library built with the experimental streaming kernel
+    # (tools/build_variant.sh stream -DADSB_WITH_STREAM_KERNEL=1 -Itools/experimental, used via ADSB_HIP_LIB)
+    # runs the whole module a second time with ADSB_KERNEL=stream when ADSB_TEST_STREAM_KERNEL=1 is set.
+    return ["tiles", "stream"] if os.environ.get("ADSB_TEST_STREAM_KERNEL") == "1" else ["tiles"]
+
+
+@pytest.fixture(scope="module", params=_kernel_kinds(), autouse=True)
 def kernel_kind(request):
-    """Every test of this module runs once per i8 tile kernel: the streaming kernel (default) and the
-    one-workgroup-per-tile kernel (ADSB_KERNEL=tiles, read at adsb_create).  i16 contexts always use the
-    tile kernel."""
+    """Every test of this module runs once per i8 kernel under test: demod_tiles (the default and only kernel
+    of the product build), and the experimental streaming kernel when asked for (see _kernel_kinds)."""
     old = os.environ.get("ADSB_KERNEL")
     os.environ["ADSB_KERNEL"] = request.param
     yield request.param

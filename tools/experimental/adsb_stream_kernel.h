@@ -413,7 +413,7 @@ __device__ __forceinline__ void stream_decode_role(const DemodArgs &p, unsigned 
                     }
                     below = row16_sum(below);
                     const bool valid = decode_candidate<ADSB_SAMPLE_I8, true>(mag, syn, stage + (have ? below : 0u) * 24, have, off,
-                                                                              tpd.sample0, l, lane, nib);
+                                                                              tpd.sample0 + p.offset_base, l, lane, nib);
                     if (valid && l == 0) atomicAdd(&misc[L::kValid + j % 3], 1u);
                 }
             }
@@ -531,7 +531,7 @@ __device__ __forceinline__ void stream_gate_role(const DemodArgs &p, unsigned ch
                     const uint32_t ci = r + g;
                     const bool have = ci < ncl;
                     unsigned char *rec = res + g * 24;
-                    const bool valid = decode_candidate<ADSB_SAMPLE_I8>(mag, syn, rec, have, have ? list[ci] : 0u, tp.sample0, l, lane);
+                    const bool valid = decode_candidate<ADSB_SAMPLE_I8>(mag, syn, rec, have, have ? list[ci] : 0u, tp.sample0 + p.offset_base, l, lane);
                     if (valid && l == 0) atomicAdd(&misc[L::kValid + i % 3], 1u);
                     if (have && base_slot != kNoBase && l < 6) {
                         uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + ci);
@@ -575,7 +575,10 @@ __global__ __launch_bounds__(kSThreads, 1) void demod_stream_i8(DemodArgs p)
             reinterpret_cast<uint32_t *>(smem + L::kOffNib)[tid] = e;
         }
         if (tid < 16) misc[tid] = 0;
-        if (blockIdx.x == 0 && tid == 0) p.hdr->retry = 0;
+        if (blockIdx.x == 0 && tid == 0) {
+            p.hdr->retry = 0;
+            if (p.count_groups) { p.hdr->flags = 0; if (p.hdr_pub) p.hdr_pub[2] = 0; } // as demod_tiles
+        }
     }
     const uint32_t G = gridDim.x;
     const uint32_t n_my = (p.tile_count - blockIdx.x + G - 1) / G; // >= 1: the grid is at most tile_count
