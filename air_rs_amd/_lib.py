@@ -120,6 +120,7 @@ PROTOTYPES = {
     "adsb_debug_lut": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adsb_debug_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adsb_debug_stamps_waves": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adsb_debug_tile_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "adsb_synth_default": (None, [_P(AdsbSynthCfg)]),
     "adsb_synth_fill_host": (C.c_int, [_P(AdsbSynthCfg), C.c_int, C.c_uint32, C.c_uint64, C.c_size_t,
                                        C.c_void_p]),
@@ -180,7 +181,10 @@ def load():
             "air_rs_amd has no CPU fallback for the demodulation path.")
     _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
+    lenient = os.environ.get("ADSB_HIP_LIB_LENIENT") == "1"  # A/B runs against libraries built from older sources
     for name, (res, args) in PROTOTYPES.items():
+        if lenient and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

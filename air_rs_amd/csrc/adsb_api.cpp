@@ -68,7 +68,8 @@ struct adsb_ctx {
     uint32_t n_grp1 = 0, n_grp2 = 0;
     uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
     uint8_t *lut = nullptr;         // i8 streaming kernel: 64 KB floor(sqrt(I^2+Q^2)) table (swizzled index)
-    unsigned long long *stamps = nullptr; // 16 cycle counters (diagnostic builds of the streaming kernel)
+    unsigned long long *stamps = nullptr; // cycle counters of diagnostic builds (16 words; 64 bytes per tile with -DADSB_TILE_STAMPS=1)
+    size_t stamps_bytes = 0;
     uint32_t stream_grid = 0;       // persistent workgroups of the streaming kernel (= CUs); 0: tile kernel
     uint32_t *tickets = nullptr;    // tile-ticket counters of the persistent tile kernel
     uint32_t persist_grid = 0;      // its grid: resident workgroup slots (CUs x 4)
@@ -253,7 +254,8 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
                 break;
             }
             // cycle counters of diagnostic builds (-DADSB_TILE_STAMPS=1, -DADSB_STAMPS=1); zeros otherwise
-            if (hipMalloc((void **)&c->stamps, 512) != hipSuccess || hipMemsetAsync(c->stamps, 0, 512, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
+            c->stamps_bytes = adsbk::tile_stamps_built() ? (size_t)c->n_tiles_max * 64 + 512 : 512;
+            if (hipMalloc((void **)&c->stamps, c->stamps_bytes) != hipSuccess || hipMemsetAsync(c->stamps, 0, c->stamps_bytes, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
             const size_t tb = sizeof(uint32_t) * 9 * adsbk::kTicketStride;
             if (hipMalloc((void **)&c->tickets, tb) != hipSuccess || hipMemsetAsync(c->tickets, 0, tb, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
             c->persist_grid = (uint32_t)n_cu * 4u;
@@ -289,6 +291,18 @@ extern "C" int adsb_debug_stamps(adsb_ctx *c, uint64_t out16[16])
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out16, c->stamps, 128, hipMemcpyDeviceToHost));
+    return ADSB_OK;
+}
+
+extern "C" int adsb_debug_tile_stamps(adsb_ctx *c, uint32_t *out, size_t max_tiles, size_t *n_tiles)
+{
+    if (!c || !n_tiles || (!out && max_tiles)) return ADSB_E_ARG;
+    if (!adsbk::tile_stamps_built() || !c->stamps) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t n = std::min<size_t>(max_tiles, c->last_tiles);
+    if (n) HIPCHK(hipMemcpy(out, c->stamps, n * 64, hipMemcpyDeviceToHost));
+    *n_tiles = n;
     return ADSB_OK;
 }
 

@@ -129,6 +129,7 @@ hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nu
 // present in -DADSB_WITH_STREAM_KERNEL=1 builds (tools/experimental/)
 hipError_t launch_build_lut(hipStream_t s, uint8_t *lut_dev);
 bool stream_kernel_built();
+bool tile_stamps_built(); // -DADSB_TILE_STAMPS=1 diagnostic build: DemodArgs::stamps holds 64 bytes per tile
 
 // field decode of an ordered frame list (count read from hdr->n_out on the device)
 hipError_t launch_decode_fields(hipStream_t s, const adsb_frame *frames, const Header *hdr, uint32_t cap,

@@ -164,45 +164,6 @@ __device__ __forceinline__ void mags8_i8(u32x4 v, uint32_t &lo, uint32_t &hi)
     hi = __builtin_amdgcn_cvt_pk_u8_f32(r[7], 3, hi);
 }
 
-// ---- i8 magnitudes from format-converting loads ---------------------------------------------------------
-// The memory pipeline can unpack and convert on the way in: a typed buffer load (data format 8_8_8_8, numeric
-// format SSCALED, D16) returns four consecutive i8 as four f16 VALUES in two VGPRs -- one IQ sample per VGPR
-// as an (I, Q) f16 pair, exact for |x| <= 128.  One v_dot2_f32_f16 with the inline constant 0.5 as accumulator
-// then gives I^2 + Q^2 + 0.5 as f32 (exact: every product and the sum are integers + 0.5 below 2^24): the
-// v_and, the integer dot product and the 2^23 subtraction of the untyped path are gone (4 instead of 5.5 issue
-// slots per sample).  No clang builtin exists for the typed load; the LLVM intrinsic is declared by its name
-// (format = dfmt | nfmt << 4: BUF_DATA_FORMAT_8_8_8_8 = 10, BUF_NUM_FORMAT_SSCALED = 3).
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ f16x4 tbuffer_load_v4f16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int format, int aux)
-    __asm("llvm.amdgcn.raw.ptr.tbuffer.load.v4f16");
-constexpr int kFmtI8x4ToF16 = 10 | (3 << 4);
-
-// Eight samples (four typed loads) -> eight n + 0.5.  VOP3P form with the constant as src2 (for the builtin hipcc
-// picks v_dot2c, which needs a v_mov per call to preload the accumulator); 3 wait states between a DOT and a
-// different VALU reading its result, and hipcc pads nothing for asm: the block ends in s_nop 2.
-__device__ __forceinline__ void dot2x8_f16(const uint32_t h[8], float f[8])
-{
-    asm("v_dot2_f32_f16 %0, %8, %8, 0.5\n\t"
-        "v_dot2_f32_f16 %1, %9, %9, 0.5\n\t"
-        "v_dot2_f32_f16 %2, %10, %10, 0.5\n\t"
-        "v_dot2_f32_f16 %3, %11, %11, 0.5\n\t"
-        "v_dot2_f32_f16 %4, %12, %12, 0.5\n\t"
-        "v_dot2_f32_f16 %5, %13, %13, 0.5\n\t"
-        "v_dot2_f32_f16 %6, %14, %14, 0.5\n\t"
-        "v_dot2_f32_f16 %7, %15, %15, 0.5\n\t"
-        "s_nop 2"
-        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
-        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(h[4]), "v"(h[5]), "v"(h[6]), "v"(h[7]));
-}
-// two samples of one typed load -> two magnitude bytes (low half of the result)
-template <int MAGMODE> __device__ __forceinline__ uint32_t mags2_from_root(float f0, float f1)
-{
-    float r0 = __builtin_amdgcn_sqrtf(f0), r1 = __builtin_amdgcn_sqrtf(f1);
-    if (MAGMODE == 2) { r0 -= 0.5f; r1 -= 0.5f; }
-    uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(r0, 0, 0u);
-    return __builtin_amdgcn_cvt_pk_u8_f32(r1, 1, w);
-}
-
 // floor(sqrt(I^2+Q^2)) for one i16 sample (n <= 2^31): n by one v_dot2_i32_i16, a float estimate rounded to
 // the nearest integer, and one exact integer correction.
 // Error budget of sqrtf((float)n) at s = sqrt(n) <= 46341: conversion to float 2^-24 relative (2^-25 after
@@ -471,9 +432,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, live ? (int)nrec : 0, 0x00020000);
 }
 
-// Diagnostic build (-DADSB_TILE_STAMPS=1; measurement only): lane 0 of waves 0 and 3 of every workgroup add the
-// shader cycles (s_memtime) they spent in each segment of a tile to DemodArgs::stamps (8 words per wave: prologue
-// up to the loads issued, phase 1 incl. the wait for the loads, barrier, phase 2, barrier, phase 3, -, tiles).
+// Diagnostic build (-DADSB_TILE_STAMPS=1; measurement only): lane 0 of waves 0 and 3 of every workgroup store the
+// shader cycles (s_memtime) they spent in each segment of a tile to DemodArgs::stamps: 16 u32 per tile (8 per
+// wave: prologue up to the loads issued, phase 1 arithmetic, barrier, phase 2, barrier, phase 3, wait for the
+// loads, and the low word of s_memrealtime at the start), plain stores at the end of the tile.
 #ifndef ADSB_TILE_STAMPS
 #define ADSB_TILE_STAMPS 0
 #endif
@@ -483,7 +445,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
         if ((tid & 63u) == 0 && (wave == 0 || wave == 3)) {                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                      \
-            if ((k) >= 0) atomicAdd(&p.stamps[(wave ? 8 : 0) + (k)], now_ - ts_prev);                          \
+            if ((k) >= 0) ts_seg[(k)] = (uint32_t)(now_ - ts_prev);                                            \
             ts_prev = now_;                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
         }                                                                                                      \
@@ -493,7 +455,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
 #endif
 
 #ifndef ADSB_PERSIST
-#define ADSB_PERSIST 0 // 1: persistent workgroups drawing tiles from per-XCD ticket counters
+#define ADSB_PERSIST 1 // 1 (product): persistent workgroups drawing tiles from per-XCD ticket counters; 0: one tile per workgroup
 #endif
 // Next tile (relative to tile_first) for a workgroup drawing from XCD `src`'s counter; moves on to the next
 // XCD's counter when one is exhausted; kNoBase when all eight are.  One lane calls this.
@@ -691,27 +653,73 @@ __device__ __forceinline__ u32x4 tile_rsrc_words(const DemodArgs &p, const TileP
 #ifndef ADSB_LOAD_AUX
 #define ADSB_LOAD_AUX 2
 #endif
-constexpr int kRawIters = (kMag + kThreads * 8 - 1) / (kThreads * 8); // 17 x 16 B per lane (i8)
-#ifndef ADSB_P1_TYPED
-#define ADSB_P1_TYPED 0 // 1: i8 phase 1 through format-converting loads (see tbuffer_load_v4f16)
-#endif
-#ifndef ADSB_TYPED_DEPTH
-#define ADSB_TYPED_DEPTH 32
-#endif
-constexpr int kTypedLoads = (kMag * 2 + kThreads * 4 - 1) / (kThreads * 4); // 65 x 4 B per lane
-constexpr int kTypedDepth = ADSB_TYPED_DEPTH;                               // loads in flight per lane
+// Phase-1 geometry: one 16-byte load = 8 i8 samples or 4 i16 samples per lane; kIters sweeps of the workgroup cover
+// the tile + halo (17 for both sample types at the default tile lengths).
+template <int ST> struct P1 {
+    static constexpr int kSPL = ST == ADSB_SAMPLE_I8 ? 8 : 4;
+    static constexpr int kIters = (TileCfg<ST>::kMagT + kThreads * kSPL - 1) / (kThreads * kSPL);
+};
+
+// All of a tile's loads are issued at once (nothing is waited for here): 17 x 16 bytes per lane = the whole tile
+// in flight.  `live == false` (there is no next tile) clips the descriptor to zero records: the loads return zeros
+// without touching memory.  The last sweep only covers the halo: whole waves past it skip it (scalar branch).
+template <int ST>
+__device__ __forceinline__ void issue_tile_loads(const DemodArgs &p, const TilePos &tp, bool live, uint32_t tid,
+                                                 u32x4 (&raw)[P1<ST>::kIters])
+{
+    constexpr int BPS = (ST == ADSB_SAMPLE_I8) ? 2 : 4;
+    __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<BPS, TileCfg<ST>::kMagT>(p, tp, live);
+    const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * P1<ST>::kSPL;
+#pragma unroll
+    for (int it = 0; it < P1<ST>::kIters; ++it)
+        if ((uint32_t)it * (kThreads * P1<ST>::kSPL) + wave_s0 < (uint32_t)TileCfg<ST>::kMagT)
+            raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
+}
+
+// raw IQ -> magnitudes in LDS (u8 for i8 input, u16 for i16)
+template <int ST, int MAGMODE>
+__device__ __forceinline__ void magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIters], typename MagT<ST>::type *mag, uint32_t tid)
+{
+    const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * P1<ST>::kSPL;
+#pragma unroll
+    for (int it = 0; it < P1<ST>::kIters; ++it) {
+        if ((uint32_t)it * (kThreads * P1<ST>::kSPL) + wave_s0 < (uint32_t)TileCfg<ST>::kMagT) {
+            const uint32_t s = (uint32_t)it * (kThreads * P1<ST>::kSPL) + tid * P1<ST>::kSPL;
+            uint32_t lo, hi;
+            if (ST == ADSB_SAMPLE_I8) mags8_i8<MAGMODE>(raw[it], lo, hi);
+            else mags4_i16(raw[it], lo, hi);
+            if (s < (uint32_t)TileCfg<ST>::kMagT) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+        }
+    }
+}
 
 #ifndef ADSB_WAVES_PER_SIMD
 #define ADSB_WAVES_PER_SIMD (kRun >= 64 ? 4 : (kRun >= 48 ? 5 : 6))
 #endif
 
+// demod_tiles: persistent workgroups, one per resident slot (4 per CU: the tile's magnitudes take 33 KB of LDS).
+// Each draws tiles from ticket counters until none is left; per tile:
+//   phase 1  the tile's raw IQ, already in flight (issued during the previous tile's phase 3), becomes
+//            magnitudes in LDS;                                             ... barrier
+//   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase);     ... barrier
+//            the NEXT tile's 17 loads per lane are issued here, into the registers phase 1 has freed
+//   phase 3  survivors are sliced, CRC-checked, repaired and written to the tile's slots while those loads
+//            are in flight;                                                  ... barrier
+// Why persistent (in-kernel cycle stamps, tools/gpu/tile_stamps.py): with one workgroup per
+// tile a slot stood empty for ~3.4 us between two workgroups (the old one's stores draining, the dispatcher
+// launching the new one) and the new one then waited ~2.3 us for its samples -- 40 % of a 14 us round in which
+// the slot's share of the VALU went unused, while inside the stamps the SIMDs were already saturated.
+// Tickets: one counter per XCD (a single address saturates at ~80 atomics/us, about the rate tiles retire at):
+// XCD x owns tiles x, x + 8, ...; a workgroup whose XCD has run dry draws from the next one, which keeps the end of
+// a launch balanced.  The ticket for tile k+1 is requested after phase 1 of tile k and read at the end of its
+// phase 2: the latency is never exposed, and nothing in the loop waits for a store to complete.  The last
+// workgroup to leave re-arms the counters for the next launch.
 template <int ST, int MAGMODE>
 __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4))) void demod_tiles(DemodArgs p)
 {
     typedef Lds<ST> L;
     typedef TileCfg<ST> TC; // tile length of this sample type
     typedef typename L::mag_t mag_t;
-    constexpr int BPS = (ST == ADSB_SAMPLE_I8) ? 2 : 4; // bytes per IQ sample
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
     mag_t *mag = reinterpret_cast<mag_t *>(smem);
@@ -727,132 +735,55 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
 #if ADSB_TILE_STAMPS
     unsigned long long ts_prev = 0;
+    uint32_t ts_seg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ts_seg[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     TSTAMP(-1);
+    ts_seg[8] = (uint32_t)ts_prev; // s_memtime next to the s_memrealtime above: the shader clock under this load
 #endif
 
-    if (tid < 112) syn[tid] = kSyn.v[tid];
-    // One tile per workgroup; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU
-    // and starts the next tile as soon as one retires, which staggers the phases of co-resident
-    // workgroups: while one waits for its samples the others keep the VALU busy.  (Persistent
-    // variants -- atomic tickets, static round-robin, register prefetch of the next tile, single-wave
-    // workgroups -- all measured slower)
-#if ADSB_PERSIST
-    // Persistent form: the grid is one workgroup per resident slot (4 per CU) and every workgroup draws tiles
-    // from ticket counters until none is left, so a slot never waits for the dispatcher to launch the next
-    // workgroup (measured per-tile fixed cost of the one-tile-per-workgroup form: ~2 us of ~15).  One counter
-    // per XCD (a single address saturates at ~80 atomics/us, about the rate tiles retire at): XCD x owns tiles
-    // x, x + 8, ...; a workgroup whose own XCD has run dry takes from the next one, so the end of the launch
-    // stays balanced.  The ticket for the NEXT tile is requested right after this tile's loads and read at the
-    // end of the tile: its latency is never exposed.  The last workgroup to leave re-arms the counters.
-    uint32_t src = 0, tries = 0; // (tid 0 only) XCD whose counter is being drawn from; counters found empty
+    // first tile: drawn synchronously (the only exposed ticket of a workgroup's life)
+    uint32_t src = 0, tries = 0; // (tid 0 only) XCD whose counter is being drawn from; counters found empty so far
     if (tid == 0) {
+#if ADSB_PERSIST
         src = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u; // HW_REG_XCC_ID[3:0]
         misc[10] = claim_tile(p, src, tries);
-    }
-    __syncthreads();
-    for (uint32_t tile_rel = misc[10]; tile_rel != kNoBase; tile_rel = misc[10]) {
-        const uint32_t tile = p.tile_first + tile_rel;
 #else
-    {
-        const uint32_t tile = p.tile_first + blockIdx.x;
+        misc[10] = blockIdx.x; // one tile per workgroup (A/B builds only)
 #endif
-        const TilePos tp = tile_pos<TC::kTileT>(p, tile);
-        const uint64_t sample0 = tp.sample0;
-        const uint32_t n_valid = tp.n_valid;
-        if (blockIdx.x == 0 && tid == 0) {
+        misc[8] = 0;  // valid-frame counter
+        misc[12] = 0; // survivor counter
+        if (blockIdx.x == 0) {
             p.hdr->retry = 0;
             if (p.count_groups) { // first pass of a launch: the ordering pass ORs this launch's flags in
                 p.hdr->flags = 0;
                 if (p.hdr_pub) p.hdr_pub[2] = 0;
             }
         }
-        if (tid == 0) { misc[8] = 0; misc[12] = 0; } // valid-frame counter, survivor counter
+    }
+    if (tid < 112) syn[tid] = kSyn.v[tid];
+    __syncthreads();
+
+    uint32_t tile_rel = misc[10];
+    if (tile_rel == kNoBase) tile_rel = 0x7FFFFFFFu; // (more workgroups than tiles) nothing to do: falls through the loop test
+    u32x4 raw[P1<ST>::kIters];
+    TilePos tp = tile_pos<TC::kTileT>(p, p.tile_first + (tile_rel < p.tile_count ? tile_rel : 0u));
+    issue_tile_loads<ST>(p, tp, tile_rel < p.tile_count, tid, raw);
+
+    while (tile_rel < p.tile_count) {
+        const uint32_t tile = p.tile_first + tile_rel;
+        const uint64_t sample0 = tp.sample0;
+        const uint32_t n_valid = tp.n_valid;
+        TSTAMP(0); // tile start (prologue / previous tile's tail)
 
         // [phase:1 magnitude (loads, stores)]
-        // ---- phase 1: raw IQ -> magnitudes in LDS ---------------------------------------------
-        {
-            __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<BPS, TC::kMagT>(p, tp);
-            if (ST == ADSB_SAMPLE_I8 && ADSB_P1_TYPED) {
-                // typed loads: load k covers bytes [1024 k, +1024) of the tile, 4 bytes (2 samples) per lane,
-                // fully coalesced; kTypedDepth of them in flight per lane, re-issued as they are consumed
-                f16x4 q[kTypedLoads];
-                const int voff = (int)tid * 4;
-                const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 2;
-#pragma unroll
-                for (int it = 0; it < kTypedDepth && it < kTypedLoads; ++it)
-                    if ((uint32_t)it * 512 + wave_s0 < (uint32_t)kMag)
-                        q[it] = tbuffer_load_v4f16(rsrc, voff + (it & 3) * 1024, (it & ~3) * 1024, kFmtI8x4ToF16, ADSB_LOAD_AUX);
-#pragma unroll
-                for (int it0 = 0; it0 < kTypedLoads; it0 += 4) {
-                    uint32_t h[8];
-                    float f[8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int it = it0 + j < kTypedLoads ? it0 + j : kTypedLoads - 1;
-                        const bool live = (uint32_t)it * 512 + wave_s0 < (uint32_t)kMag; // wave-uniform
-                        const uint2 w = live ? __builtin_bit_cast(uint2, q[it]) : make_uint2(0u, 0u);
-                        h[2 * j] = w.x;
-                        h[2 * j + 1] = w.y;
-                    }
-                    dot2x8_f16(h, f);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int it = it0 + j;
-                        if (it < kTypedLoads) {
-                            const uint32_t s0 = (uint32_t)it * 512 + tid * 2;
-                            const uint32_t m2 = mags2_from_root<MAGMODE>(f[2 * j], f[2 * j + 1]);
-                            if ((uint32_t)it * 512 + wave_s0 < (uint32_t)kMag && s0 < (uint32_t)kMag)
-                                *reinterpret_cast<uint16_t *>(mag + s0) = (uint16_t)m2;
-                            const int nx = it + kTypedDepth;
-                            if (nx < kTypedLoads && (uint32_t)nx * 512 + wave_s0 < (uint32_t)kMag)
-                                q[nx] = tbuffer_load_v4f16(rsrc, voff + (nx & 3) * 1024, (nx & ~3) * 1024, kFmtI8x4ToF16, ADSB_LOAD_AUX);
-                        }
-                    }
-                }
-            } else if (ST == ADSB_SAMPLE_I8) {
-                u32x4 raw[kRawIters];
-                // the last sweep only covers the halo: whole waves past it skip it (scalar branch)
-                const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 8;
-#pragma unroll
-                for (int it = 0; it < kRawIters; ++it)
-                    if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag)
-                        raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
-                TSTAMP(0); // prologue, loads issued
+        // ---- phase 1: raw IQ (in flight since the previous tile's phase 3) -> magnitudes in LDS -------------
 #if ADSB_TILE_STAMPS
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
-                TSTAMP(6);                                       // ... as its own segment
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
+        TSTAMP(6);                                       // ... as its own segment
 #endif
-#pragma unroll
-                for (int it = 0; it < kRawIters; ++it) {
-                    if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)kMag) {
-                        uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
-                        uint32_t lo, hi;
-                        mags8_i8<MAGMODE>(raw[it], lo, hi);
-                        if (s < (uint32_t)kMag) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
-                    }
-                }
-            } else {
-                constexpr int kIters = (TC::kMagT + kThreads * 4 - 1) / (kThreads * 4); // 17 (33 with 64-offset runs)
-                // all of the tile's loads in flight before the first magnitude, like the i8 branch
-                u32x4 raw[kIters];
-                const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 4;
-#pragma unroll
-                for (int it = 0; it < kIters; ++it)
-                    if ((uint32_t)it * (kThreads * 4) + wave_s0 < (uint32_t)TC::kMagT)
-                        raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
-#pragma unroll
-                for (int it = 0; it < kIters; ++it) {
-                    if ((uint32_t)it * (kThreads * 4) + wave_s0 < (uint32_t)TC::kMagT) {
-                        const uint32_t s = (uint32_t)it * (kThreads * 4) + tid * 4;
-                        uint32_t lo, hi;
-                        mags4_i16(raw[it], lo, hi);
-                        if (s < (uint32_t)TC::kMagT) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
-                    }
-                }
-            }
-        }
+        magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
 #if ADSB_PERSIST
-        uint32_t next_ticket = 0; // requested now, read after phase 3
+        uint32_t next_ticket = 0; // requested now, read at the end of phase 2
         if (tid == 0) next_ticket = atomicAdd(&p.tickets[src * kTicketStride], 1u);
 #endif
         TSTAMP(1); // phase 1 arithmetic
@@ -867,9 +798,27 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
         gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
 #endif
+        if (tid == 0) { // which tile comes next (published by the barrier below)
+            uint32_t rel = kNoBase;
+#if ADSB_PERSIST
+            rel = src + 8u * next_ticket;
+            if (rel >= p.tile_count) { // this XCD's tiles are gone: draw from the others (rare: end of the launch)
+                src = (src + 1u) & 7u;
+                ++tries;
+                rel = claim_tile(p, src, tries);
+            }
+#endif
+            misc[11] = rel;
+        }
         TSTAMP(3); // phase 2
         __syncthreads();
         TSTAMP(4); // barrier
+
+        // ---- the next tile's loads go out now and fly during phase 3 ------------------------------------------
+        const uint32_t next_rel = misc[11];
+        const bool have_next = next_rel < p.tile_count;
+        const TilePos tpn = tile_pos<TC::kTileT>(p, p.tile_first + (have_next ? next_rel : 0u));
+        issue_tile_loads<ST>(p, tpn, have_next, tid, raw);
 
         // [phase:3 list, slots, records]
         // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
@@ -969,10 +918,14 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         }
         TSTAMP(5); // phase 3
 #if ADSB_TILE_STAMPS
-        if (tid == 0) atomicAdd(&p.stamps[7], 1ull);
-        if (tid == 192) atomicAdd(&p.stamps[15], 1ull);
+        if ((tid & 63u) == 0 && (wave == 0 || wave == 3)) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(p.stamps) + (size_t)tile * 16 + (wave ? 8 : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k] = ts_seg[k];
+            if (wave) dst[6] = ts_seg[8]; // wave 3's load wait is wave 0's: its slot carries the s_memtime stamp
+        }
 #endif
-        // (total == 0: nothing was added to misc[8] since tid 0 cleared it before the phase-1 barrier)
+        // (total == 0: nothing was added to misc[8] since tid 0 cleared it)
         if (tid == 0) {
             Seg e;
             e.base = simple ? tile * kQuota : misc[9];
@@ -984,22 +937,18 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 atomicAdd(&p.grp1[tile >> kGrpShift], e.valid);
                 atomicAdd(&p.grp2[(tile >> (2 * kGrpShift)) * kGrp2Shards + ((tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
             }
-#if ADSB_PERSIST
-            uint32_t rel = src + 8u * next_ticket;
-            if (rel >= p.tile_count) { // this XCD's tiles are gone: take from the others
-                src = (src + 1u) & 7u;
-                ++tries;
-                rel = claim_tile(p, src, tries);
-            }
-            misc[8] = 0;  // valid-frame counter, survivor counter of the next tile
+            misc[8] = 0;  // for the next tile
             misc[12] = 0;
-            misc[10] = rel;
-#endif
         }
-#if ADSB_PERSIST
-        __syncthreads(); // every wave is done with this tile's LDS; misc[10] is the next tile
+        __syncthreads(); // every wave is done with this tile's LDS
+#if ADSB_TILE_STAMPS
+        ts_seg[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        ts_seg[8] = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
+        tile_rel = have_next ? next_rel : 0x7FFFFFFFu;
+        tp = tpn;
     }
+    // [phase:end]
 #if ADSB_PERSIST
     if (tid == 0) { // the last workgroup to leave re-arms the counters for the next launch
         const uint32_t left = atomicAdd(&p.tickets[8 * kTicketStride], 1u);
@@ -1009,7 +958,6 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         }
     }
 #endif
-    // [phase:end]
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
@@ -1044,6 +992,7 @@ static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &
 hipError_t launch_build_lut(hipStream_t, uint8_t *) { return hipErrorNotSupported; }
 #endif
 bool stream_kernel_built() { return ADSB_WITH_STREAM_KERNEL != 0; }
+bool tile_stamps_built() { return ADSB_TILE_STAMPS != 0; }
 
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
                         hipEvent_t e0, hipEvent_t e1)

@@ -173,6 +173,13 @@ class AdsbDemod:
         L.check(self._lib.adsb_debug_stamps(self._h, out.ctypes.data), "adsb_debug_stamps")
         return out
 
+    def tile_stamps(self, max_tiles=1 << 20):
+        """Diagnostic builds (-DADSB_TILE_STAMPS=1): (n_tiles, 16) uint32 of the last launch."""
+        out = np.zeros((max_tiles, 16), dtype=np.uint32)
+        n = C.c_size_t()
+        L.check(self._lib.adsb_debug_tile_stamps(self._h, out.ctypes.data, max_tiles, C.byref(n)), "adsb_debug_tile_stamps")
+        return out[:n.value].copy()
+
     def stamps_waves(self):
         out = np.zeros(16, dtype=np.uint64)
         L.check(self._lib.adsb_debug_stamps_waves(self._h, out.ctypes.data), "adsb_debug_stamps_waves")

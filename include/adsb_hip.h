@@ -257,6 +257,10 @@ int adsb_debug_lut(adsb_ctx *ctx, uint8_t *table_host65536);
 /* Diagnostic builds of the streaming kernel (-DADSB_STAMPS=1) only: per-segment shader-cycle sums of
  * workgroup 0 over the last launch (zeros in a normal build). */
 int adsb_debug_stamps(adsb_ctx *ctx, uint64_t out16[16]);
+/* Diagnostic builds of demod_tiles (-DADSB_TILE_STAMPS=1) only: 16 uint32 per tile of the last launch (waves 0
+ * and 3 of the tile's workgroup, 8 each: shader cycles in prologue, phase 1, barrier, phase 2, barrier, phase 3,
+ * wait for the loads; s_memrealtime at start).  ADSB_E_STATE in a normal build. */
+int adsb_debug_tile_stamps(adsb_ctx *ctx, uint32_t *out16_per_tile, size_t max_tiles, size_t *n_tiles);
 /* Same builds: cycles each of workgroup 0's 16 waves spent between leaving one round barrier and reaching
  * the next, summed over the last launch (which wave a round waits for). */
 int adsb_debug_stamps_waves(adsb_ctx *ctx, uint64_t out16[16]);
