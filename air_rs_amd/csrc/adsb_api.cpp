@@ -71,8 +71,6 @@ struct adsb_ctx {
     unsigned long long *stamps = nullptr; // cycle counters of diagnostic builds (16 words; 64 bytes per tile with -DADSB_TILE_STAMPS=1)
     size_t stamps_bytes = 0;
     uint32_t stream_grid = 0;       // persistent workgroups of the streaming kernel (= CUs); 0: tile kernel
-    uint32_t *tickets = nullptr;    // tile-ticket counters of the persistent tile kernel
-    uint32_t persist_grid = 0;      // its grid: resident workgroup slots (CUs x 4)
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
 
@@ -150,7 +148,6 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     (void)hipFree(c->scratch);
     (void)hipFree(c->lut);
     (void)hipFree(c->stamps);
-    (void)hipFree(c->tickets);
     (void)hipFree(c->grp);
     if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
@@ -247,20 +244,9 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         else if (probe[1] == want) c->mag_mode = 1;
         else c->mag_mode = 2;
         if (const char *force = getenv("ADSB_FORCE_MAG_MODE")) c->mag_mode = atoi(force) % 3;
-        {
-            int n_cu = 0;
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) {
-                fail(ADSB_E_NODEVICE);
-                break;
-            }
-            // cycle counters of diagnostic builds (-DADSB_TILE_STAMPS=1, -DADSB_STAMPS=1); zeros otherwise
-            c->stamps_bytes = adsbk::tile_stamps_built() ? (size_t)c->n_tiles_max * 64 + 512 : 512;
-            if (hipMalloc((void **)&c->stamps, c->stamps_bytes) != hipSuccess || hipMemsetAsync(c->stamps, 0, c->stamps_bytes, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
-            const size_t tb = sizeof(uint32_t) * 9 * adsbk::kTicketStride;
-            if (hipMalloc((void **)&c->tickets, tb) != hipSuccess || hipMemsetAsync(c->tickets, 0, tb, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
-            c->persist_grid = (uint32_t)n_cu * 4u;
-            if (const char *g = getenv("ADSB_PERSIST_GRID")) { int v = atoi(g); if (v > 0) c->persist_grid = (uint32_t)v; }
-        }
+        // cycle counters of diagnostic builds (-DADSB_TILE_STAMPS=1, -DADSB_STAMPS=1); zeros otherwise
+        c->stamps_bytes = adsbk::tile_stamps_built() ? (size_t)c->n_tiles_max * 64 + 512 : 512;
+        if (hipMalloc((void **)&c->stamps, c->stamps_bytes) != hipSuccess || hipMemsetAsync(c->stamps, 0, c->stamps_bytes, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
         if (want_stream) {
             int n_cu = 0;
             if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) {
@@ -352,8 +338,6 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.lut = c->lut;
     a.stream_grid = c->stream_grid;
     a.stamps = c->stamps;
-    a.tickets = c->tickets;
-    a.persist_grid = c->persist_grid;
     return a;
 }
 

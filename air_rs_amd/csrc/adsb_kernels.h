@@ -47,7 +47,6 @@ constexpr uint32_t kQuota = 32;
 // Level-2 group counters are sharded 16 ways by the level-1 group index so that the ~1000 tiles in
 // flight at any time never pile onto one address.
 constexpr int kGrp2Shards = 16;
-constexpr int kTicketStride = 32; // words between ticket counters (one 128-byte line each)
 
 // One entry per tile, written unconditionally by the demod kernel.
 struct Seg {
@@ -90,8 +89,6 @@ struct DemodArgs {
     // (number of CUs); stream_grid == 0 selects the one-workgroup-per-tile kernel
     const uint8_t *lut;
     uint32_t stream_grid;
-    uint32_t *tickets;         // persistent tile kernel: 9 counters kTicketStride words apart (8 XCDs + "workgroups left")
-    uint32_t persist_grid;     // resident workgroup slots (CUs x 4); 0: one workgroup per tile
     unsigned long long *stamps; // diagnostic builds (-DADSB_STAMPS=1) only: 16 cycle counters of workgroup 0
 };
 

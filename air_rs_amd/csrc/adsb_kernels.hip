@@ -36,6 +36,7 @@ namespace adsbk {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// [phase:2 gate: min/max (helpers)]
 // ---- small device helpers -------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b)
 {
@@ -272,6 +273,7 @@ template <int ST> struct Lds {
     static constexpr int kTotal = kOffMisc + 64;
 };
 
+// [phase:2 gate: unpack (helpers)]
 // Packed pair for sample k of a lane's two runs: low half = run A, high half = run B.
 template <int ST>
 __device__ __forceinline__ uint32_t pair_at(const uint32_t *ra, const uint32_t *rb, int k)
@@ -453,22 +455,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
 #else
 #define TSTAMP(k) do { } while (0)
 #endif
-
-#ifndef ADSB_PERSIST
-#define ADSB_PERSIST 1 // 1 (product): persistent workgroups drawing tiles from per-XCD ticket counters; 0: one tile per workgroup
-#endif
-// Next tile (relative to tile_first) for a workgroup drawing from XCD `src`'s counter; moves on to the next
-// XCD's counter when one is exhausted; kNoBase when all eight are.  One lane calls this.
-__device__ __forceinline__ uint32_t claim_tile(const DemodArgs &p, uint32_t &src, uint32_t &tries)
-{
-    while (tries < 8u) {
-        const uint32_t rel = src + 8u * atomicAdd(&p.tickets[src * kTicketStride], 1u);
-        if (rel < p.tile_count) return rel;
-        src = (src + 1u) & 7u;
-        ++tries;
-    }
-    return kNoBase;
-}
 
 #ifndef ADSB_ABL_PHASES
 #define ADSB_ABL_PHASES 3 // measurement only (no frames come out below 3): 1 = magnitudes only, 2 = magnitudes + gate
@@ -653,6 +639,7 @@ __device__ __forceinline__ u32x4 tile_rsrc_words(const DemodArgs &p, const TileP
 #ifndef ADSB_LOAD_AUX
 #define ADSB_LOAD_AUX 2
 #endif
+// [phase:1 magnitude (loads, stores: helpers)]
 // Phase-1 geometry: one 16-byte load = 8 i8 samples or 4 i16 samples per lane; kIters sweeps of the workgroup cover
 // the tile + halo (17 for both sample types at the default tile lengths).
 template <int ST> struct P1 {
@@ -693,27 +680,22 @@ __device__ __forceinline__ void magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIt
     }
 }
 
+// [phase:end]
 #ifndef ADSB_WAVES_PER_SIMD
 #define ADSB_WAVES_PER_SIMD (kRun >= 64 ? 4 : (kRun >= 48 ? 5 : 6))
 #endif
 
-// demod_tiles: persistent workgroups, one per resident slot (4 per CU: the tile's magnitudes take 33 KB of LDS).
-// Each draws tiles from ticket counters until none is left; per tile:
-//   phase 1  the tile's raw IQ, already in flight (issued during the previous tile's phase 3), becomes
-//            magnitudes in LDS;                                             ... barrier
-//   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase);     ... barrier
-//            the NEXT tile's 17 loads per lane are issued here, into the registers phase 1 has freed
-//   phase 3  survivors are sliced, CRC-checked, repaired and written to the tile's slots while those loads
-//            are in flight;                                                  ... barrier
-// Why persistent (in-kernel cycle stamps, tools/gpu/tile_stamps.py): with one workgroup per
-// tile a slot stood empty for ~3.4 us between two workgroups (the old one's stores draining, the dispatcher
-// launching the new one) and the new one then waited ~2.3 us for its samples -- 40 % of a 14 us round in which
-// the slot's share of the VALU went unused, while inside the stamps the SIMDs were already saturated.
-// Tickets: one counter per XCD (a single address saturates at ~80 atomics/us, about the rate tiles retire at):
-// XCD x owns tiles x, x + 8, ...; a workgroup whose XCD has run dry draws from the next one, which keeps the end of
-// a launch balanced.  The ticket for tile k+1 is requested after phase 1 of tile k and read at the end of its
-// phase 2: the latency is never exposed, and nothing in the loop waits for a store to complete.  The last
-// workgroup to leave re-arms the counters for the next launch.
+// demod_tiles: one workgroup = one tile; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU (the
+// tile's magnitudes take 33 KB of LDS) and starts the next tile as soon as one retires, which staggers the phases of
+// co-resident workgroups.  Per tile:
+//   phase 1  17 x 16 bytes per lane of raw IQ, all in flight at once, become magnitudes in LDS;      ... barrier
+//   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase);                                ... barrier
+//   phase 3  survivors are sliced, CRC-checked, repaired and written to the tile's slots.
+// Measured alternatives: persistent workgroups drawing tiles from per-XCD ticket counters with
+// the next tile's loads issued before phase 3 (no slot ever waits for the dispatcher or for its samples) run the same
+// tile in ~10 % more VALU instructions (loop-carried registers, SGPR spills) and come out 7 % slower: in-kernel cycle
+// stamps (tools/gpu/tile_stamps.py) show the SIMDs VALU-saturated while any three of the four slots compute, so
+// filling the gaps buys nothing -- the instruction count is what bounds this kernel.
 template <int ST, int MAGMODE>
 __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4))) void demod_tiles(DemodArgs p)
 {
@@ -740,52 +722,34 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     TSTAMP(-1);
     ts_seg[8] = (uint32_t)ts_prev; // s_memtime next to the s_memrealtime above: the shader clock under this load
 #endif
-
-    // first tile: drawn synchronously (the only exposed ticket of a workgroup's life)
-    uint32_t src = 0, tries = 0; // (tid 0 only) XCD whose counter is being drawn from; counters found empty so far
-    if (tid == 0) {
-#if ADSB_PERSIST
-        src = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u; // HW_REG_XCC_ID[3:0]
-        misc[10] = claim_tile(p, src, tries);
-#else
-        misc[10] = blockIdx.x; // one tile per workgroup (A/B builds only)
-#endif
-        misc[8] = 0;  // valid-frame counter
-        misc[12] = 0; // survivor counter
-        if (blockIdx.x == 0) {
-            p.hdr->retry = 0;
-            if (p.count_groups) { // first pass of a launch: the ordering pass ORs this launch's flags in
-                p.hdr->flags = 0;
-                if (p.hdr_pub) p.hdr_pub[2] = 0;
-            }
-        }
-    }
-    if (tid < 112) syn[tid] = kSyn.v[tid];
-    __syncthreads();
-
-    uint32_t tile_rel = misc[10];
-    if (tile_rel == kNoBase) tile_rel = 0x7FFFFFFFu; // (more workgroups than tiles) nothing to do: falls through the loop test
-    u32x4 raw[P1<ST>::kIters];
-    TilePos tp = tile_pos<TC::kTileT>(p, p.tile_first + (tile_rel < p.tile_count ? tile_rel : 0u));
-    issue_tile_loads<ST>(p, tp, tile_rel < p.tile_count, tid, raw);
-
-    while (tile_rel < p.tile_count) {
-        const uint32_t tile = p.tile_first + tile_rel;
+    {
+        const uint32_t tile = p.tile_first + blockIdx.x;
+        const TilePos tp = tile_pos<TC::kTileT>(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
-        TSTAMP(0); // tile start (prologue / previous tile's tail)
 
         // [phase:1 magnitude (loads, stores)]
-        // ---- phase 1: raw IQ (in flight since the previous tile's phase 3) -> magnitudes in LDS -------------
+        // ---- phase 1: raw IQ -> magnitudes in LDS; the loads go out before anything else ----------------------
+        u32x4 raw[P1<ST>::kIters];
+        issue_tile_loads<ST>(p, tp, true, tid, raw);
+        TSTAMP(0); // prologue, loads issued
+        if (tid < 112) syn[tid] = kSyn.v[tid];
+        if (tid == 0) {
+            misc[8] = 0;  // valid-frame counter
+            misc[12] = 0; // survivor counter
+            if (blockIdx.x == 0) {
+                p.hdr->retry = 0;
+                if (p.count_groups) { // first pass of a launch: the ordering pass ORs this launch's flags in
+                    p.hdr->flags = 0;
+                    if (p.hdr_pub) p.hdr_pub[2] = 0;
+                }
+            }
+        }
 #if ADSB_TILE_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
         TSTAMP(6);                                       // ... as its own segment
 #endif
         magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
-#if ADSB_PERSIST
-        uint32_t next_ticket = 0; // requested now, read at the end of phase 2
-        if (tid == 0) next_ticket = atomicAdd(&p.tickets[src * kTicketStride], 1u);
-#endif
         TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
         TSTAMP(2); // barrier
@@ -798,27 +762,9 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
         gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
 #endif
-        if (tid == 0) { // which tile comes next (published by the barrier below)
-            uint32_t rel = kNoBase;
-#if ADSB_PERSIST
-            rel = src + 8u * next_ticket;
-            if (rel >= p.tile_count) { // this XCD's tiles are gone: draw from the others (rare: end of the launch)
-                src = (src + 1u) & 7u;
-                ++tries;
-                rel = claim_tile(p, src, tries);
-            }
-#endif
-            misc[11] = rel;
-        }
         TSTAMP(3); // phase 2
         __syncthreads();
         TSTAMP(4); // barrier
-
-        // ---- the next tile's loads go out now and fly during phase 3 ------------------------------------------
-        const uint32_t next_rel = misc[11];
-        const bool have_next = next_rel < p.tile_count;
-        const TilePos tpn = tile_pos<TC::kTileT>(p, p.tile_first + (have_next ? next_rel : 0u));
-        issue_tile_loads<ST>(p, tpn, have_next, tid, raw);
 
         // [phase:3 list, slots, records]
         // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
@@ -925,7 +871,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
             if (wave) dst[6] = ts_seg[8]; // wave 3's load wait is wave 0's: its slot carries the s_memtime stamp
         }
 #endif
-        // (total == 0: nothing was added to misc[8] since tid 0 cleared it)
+        // (total == 0: nothing was added to misc[8] since tid 0 cleared it before the phase-1 barrier)
         if (tid == 0) {
             Seg e;
             e.base = simple ? tile * kQuota : misc[9];
@@ -937,27 +883,9 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 atomicAdd(&p.grp1[tile >> kGrpShift], e.valid);
                 atomicAdd(&p.grp2[(tile >> (2 * kGrpShift)) * kGrp2Shards + ((tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
             }
-            misc[8] = 0;  // for the next tile
-            misc[12] = 0;
         }
-        __syncthreads(); // every wave is done with this tile's LDS
-#if ADSB_TILE_STAMPS
-        ts_seg[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        ts_seg[8] = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
-        tile_rel = have_next ? next_rel : 0x7FFFFFFFu;
-        tp = tpn;
     }
     // [phase:end]
-#if ADSB_PERSIST
-    if (tid == 0) { // the last workgroup to leave re-arms the counters for the next launch
-        const uint32_t left = atomicAdd(&p.tickets[8 * kTicketStride], 1u);
-        if (left == gridDim.x - 1) {
-#pragma unroll
-            for (int x = 0; x <= 8; ++x) __hip_atomic_store(&p.tickets[x * kTicketStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-#endif
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
@@ -967,9 +895,6 @@ template <int ST>
 static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &a, uint32_t grid_x,
                                   hipEvent_t e0, hipEvent_t e1)
 {
-#if ADSB_PERSIST
-    if (a.persist_grid && grid_x > a.persist_grid) grid_x = a.persist_grid;
-#endif
     dim3 grid(grid_x), block(kThreads);
     switch (mag_mode) {
     case 0: hipExtLaunchKernelGGL((demod_tiles<ST, 0>), grid, block, 0, s, e0, e1, 0, a); break;
