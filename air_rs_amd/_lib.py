@@ -116,6 +116,7 @@ PROTOTYPES = {
     "adsb_time_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, _P(C.c_double)]),
     "adsb_debug_magnitudes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "adsb_debug_mag_mode": (C.c_int, [C.c_void_p]),
+    "adsb_debug_fused_pass_only": (C.c_int, [C.c_void_p, C.c_int]),
     "adsb_debug_kernel": (C.c_int, [C.c_void_p]),
     "adsb_debug_lut": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adsb_debug_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -59,6 +59,7 @@ struct adsb_ctx {
     size_t ext_frames = 0;          // frame capacity of ext_blob
     adsb_frame *last_out = nullptr; // where the last launch's ordered list went
     uint32_t last_cap = 0;
+    bool fused_pass_only = false;   // adsb_debug_fused_pass_only (measurement)
     uint64_t stream_base = 0;       // adsb_set_stream_base: added to the offsets of the following launches
     uint64_t last_base = 0;         // ... of the last launch (re-runs of its tiles use the same)
     uint32_t launch_idx = 0;        // launches so far
@@ -267,6 +268,12 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
 
 extern "C" void *adsb_stream(adsb_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int adsb_sample_type(const adsb_ctx *c) { return c ? c->cfg.sample_type : ADSB_E_ARG; }
+extern "C" int adsb_debug_fused_pass_only(adsb_ctx *c, int on)
+{
+    if (!c) return ADSB_E_ARG;
+    c->fused_pass_only = on != 0;
+    return ADSB_OK;
+}
 extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
 extern "C" int adsb_debug_kernel(adsb_ctx *c) { return c ? (c->stream_grid ? 1 : 0) : ADSB_E_ARG; }
 
@@ -327,6 +334,7 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.tile_count = tile_count;
     a.count_groups = count_groups ? 1u : 0u;
     a.offset_base = c->last_base;
+    a.fused_pass_only = c->fused_pass_only ? 1u : 0u;
     a.seg = r.seg;
     a.slots = r.slots;
     a.pool_first = c->n_tiles_max * adsbk::kQuota;

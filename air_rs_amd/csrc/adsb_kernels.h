@@ -77,6 +77,7 @@ struct DemodArgs {
     uint32_t tile_first;       // global tile id of blockIdx.x == 0
     uint32_t tile_count;       // workgroups in this launch
     uint32_t count_groups;     // 1: add Seg::valid into grp1/grp2; 0: re-run of known tiles
+    uint32_t fused_pass_only;  // measurement (adsb_debug_fused_pass_only): magnitude + gate only, survivors counted but not decoded
     uint64_t offset_base;      // added to every frame's offset (adsb_set_stream_base: position of sample 0 in a longer stream)
     Seg *seg;
     adsb_frame *slots;         // [n_tiles_max * kQuota] fixed region, then the pool

@@ -772,6 +772,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
 #if ADSB_ABL_PHASES < 3
         if (total != 0x7FFFFFFFu) total = 0; // survivors are counted (phase 2 stays alive) but not decoded
 #endif
+        if (p.fused_pass_only) total = 0; // bench.py's "fused magnitude+preamble pass" figure (one scalar select)
         const bool dense = total > (uint32_t)kSparseCap;
         u32x4 cw = {0, 0, 0, 0};
         uint32_t cnt = 0, my_first = 0;

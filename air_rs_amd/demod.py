@@ -173,6 +173,10 @@ class AdsbDemod:
         L.check(self._lib.adsb_debug_stamps(self._h, out.ctypes.data), "adsb_debug_stamps")
         return out
 
+    def fused_pass_only(self, on=True):
+        """Measurement only: following launches stop after the fused magnitude + gate pass (no frames)."""
+        L.check(self._lib.adsb_debug_fused_pass_only(self._h, 1 if on else 0), "adsb_debug_fused_pass_only")
+
     def tile_stamps(self, max_tiles=1 << 20):
         """Diagnostic builds (-DADSB_TILE_STAMPS=1): (n_tiles, 16) uint32 of the last launch."""
         out = np.zeros((max_tiles, 16), dtype=np.uint32)

@@ -244,6 +244,10 @@ int adsb_debug_magnitudes(adsb_ctx *ctx, const void *iq_host, size_t n_samples,
 /* How v_cvt_pk_u8_f32 was found to round on this device: 0 truncates, 1 truncates under
  * MODE.fp_round = toward-zero, 2 rounds to nearest (kernel subtracts 0.5 first). */
 int adsb_debug_mag_mode(adsb_ctx *ctx);
+/* Measurement only (bench.py's roofline.fused_pass): with on != 0 the following launches run the fused
+ * magnitude + preamble/DF17 pass of demod_tiles and stop there -- gate survivors are counted but not sliced or
+ * CRC-checked, so NO frames come out.  on = 0 restores the full path. */
+int adsb_debug_fused_pass_only(adsb_ctx *ctx, int on);
 /* Which kernel the context launches: 0 = demod_tiles, one workgroup per tile -- the only kernel of the product
  * build, for i8 and i16 alike.  1 = the experimental streaming kernel (one persistent workgroup per CU,
  * magnitudes by table lookup), which exists only in libraries built with -DADSB_WITH_STREAM_KERNEL=1
