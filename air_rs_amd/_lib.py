@@ -23,6 +23,8 @@ ADSB_FLAG_INCOMPLETE = 0x2
 ADSB_SAMPLE_I8 = 0
 ADSB_SAMPLE_I16 = 1
 ADSB_MSG_AIRCRAFT_ID, ADSB_MSG_AIRCRAFT_POSITION, ADSB_MSG_UNKNOWN = 0, 1, 2
+ADSB_REPLAY_CARRY, ADSB_REPLAY_SEND_TAIL = 0x1, 0x2
+ADSB_FILE_C16, ADSB_FILE_U8 = 0, 1
 
 
 class AdsbFrame(C.Structure):
@@ -34,6 +36,10 @@ class AdsbCfg(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("sample_type", C.c_int32),
                 ("max_channels", C.c_uint32), ("max_samples", C.c_uint64), ("max_out", C.c_uint64),
                 ("stream", C.c_void_p), ("host_staging", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class AdsbFeedCfg(C.Structure):
+    _fields_ = [("max_chunk", C.c_size_t), ("carry", C.c_uint32), ("ring_slots", C.c_uint32)]
 
 
 class AdsbSynthCfg(C.Structure):
@@ -109,6 +115,12 @@ PROTOTYPES = {
     "adsb_stream": (C.c_void_p, [C.c_void_p]),
     "adsb_sample_type": (C.c_int, [C.c_void_p]),
     "adsb_stream_wait_results": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adsb_feed_open": (C.c_int, [C.c_void_p, _P(AdsbFeedCfg), _P(C.c_void_p)]),
+    "adsb_feed_acquire": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
+    "adsb_feed_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_feed_pop": (C.c_int, [C.c_void_p, _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint32), _P(C.c_uint64)]),
+    "adsb_feed_in_flight": (C.c_int, [C.c_void_p]),
+    "adsb_feed_close": (None, [C.c_void_p]),
     "adsb_set_result_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_set_stream_base": (C.c_int, [C.c_void_p, C.c_uint64]),
     "adsb_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -138,6 +150,11 @@ PROTOTYPES = {
                                          C.c_char_p, C.c_size_t, _P(C.c_size_t)]),
     "adsb_pipeline_playback_carry": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t,
                                                _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint64)]),
+    "adsb_pipeline_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                    _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint64),
+                                    C.c_char_p, C.c_size_t, _P(C.c_size_t)]),
+    "adsb_replay_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_size_t, C.c_uint32, _P(AdsbFrame), C.c_size_t,
+                                   _P(C.c_size_t), _P(C.c_uint64), _P(C.c_uint64), C.c_char_p, C.c_size_t, _P(C.c_size_t)]),
     "adsb_load_c16": (C.c_int, [C.c_char_p, _P(_P(C.c_int16)), _P(C.c_size_t)]),
     "adsb_save_c16": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
     "adsb_load_u8": (C.c_int, [C.c_char_p, _P(_P(C.c_int8)), _P(C.c_size_t)]),

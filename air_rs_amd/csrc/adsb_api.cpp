@@ -41,6 +41,15 @@ struct adsb_ctx {
         uint64_t *chan_counts = nullptr; // [max_channels]
         hipEvent_t k_done = nullptr, g_done = nullptr;
         bool g_pending = false;
+        // the launch whose results this set holds (the streaming front end fetches the older of two launches
+        // in flight: view_launch() makes it the one the fetch / re-plan code below works on)
+        struct Launch {
+            const void *iq = nullptr;
+            uint32_t channels = 0, tpc = 0, tiles = 0, cap = 0, idx = 0;
+            uint64_t samples = 0, stride = 0, base = 0;
+            adsb_frame *out = nullptr;
+            bool valid = false;
+        } li;
     } rs[2];
     hipStream_t aux = nullptr;      // ordering pass + result copies (== stream unless ADSB_OVERLAP_ORDERING=1)
     bool own_aux = false;
@@ -433,9 +442,24 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_out = c->ext_blob ? reinterpret_cast<adsb_frame *>(static_cast<char *>(c->ext_blob) + 32) : r.out;
     c->last_cap = c->ext_blob ? (uint32_t)std::min<size_t>(c->ext_frames, c->cfg.max_out) : (uint32_t)c->cfg.max_out;
     c->last = i & 1u;
+    r.li.iq = c->last_iq; r.li.channels = c->last_channels; r.li.samples = c->last_samples; r.li.stride = c->last_stride;
+    r.li.base = c->last_base; r.li.tpc = c->last_tpc; r.li.tiles = c->last_tiles; r.li.out = c->last_out;
+    r.li.cap = c->last_cap; r.li.idx = i; r.li.valid = true;
     c->launch_idx = i + 1u;
     if (ev && c->last_tiles) c->ev_count++;
     return ADSB_OK;
+}
+
+// Makes result set `set` (launch li.idx) the launch every fetch / re-plan function below refers to.  Only the
+// streaming front end looks at anything but the newest launch; it restores the newest before enqueueing again.
+static void view_launch(adsb_ctx *c, uint32_t set)
+{
+    const adsb_ctx::ResultSet::Launch &li = c->rs[set].li;
+    c->last = set;
+    c->last_iq = li.iq; c->last_channels = li.channels; c->last_samples = li.samples; c->last_stride = li.stride;
+    c->last_base = li.base; c->last_tpc = li.tpc; c->last_tiles = li.tiles; c->last_out = li.out; c->last_cap = li.cap;
+    c->fields_current = false;
+    c->trk_done = false;
 }
 
 // Slot-pool overflow (far more gate survivors than max_out + one tile): redo the tiles that feed
@@ -446,7 +470,7 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
     HIPCHK(hipStreamSynchronize(c->aux));
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t n = c->last_tiles;
-    const uint32_t grp_set = (c->launch_idx + 2u) % 3u; // == (launch_idx - 1) % 3: read-only here
+    const uint32_t grp_set = r.li.idx % 3u; // the launch's own counter set (not read on this path: positions are host-planned)
     std::vector<adsbk::Seg> seg(n);
     HIPCHK(hipMemcpyAsync(seg.data(), r.seg, sizeof(adsbk::Seg) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -840,5 +864,225 @@ extern "C" int adsb_synth_fill_device(adsb_ctx *c, const adsb_synth_cfg *cfg, ui
     if (!c || !synth_ok(cfg) || (!iq_dev && n)) return ADSB_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(adsbk::launch_synth(c->stream, *cfg, c->cfg.sample_type, channel, first, n, iq_dev));
+    return ADSB_OK;
+}
+
+// ---- streaming front end (reference: the Vec-per-recv loop of src/adsb.rs:95-98 and its feeders,
+// adsb.rs:54-89) --------------------------------------------------------------------------------------------
+// Buffers arrive on the host one after the other.  Each is copied into a slot of a PINNED host ring (or was
+// written there by the producer: adsb_feed_acquire), goes to one of two device staging slots by asynchronous DMA
+// on a copy stream, and is demodulated on the ctx stream -- so the copy of buffer k+1 overlaps the kernels of
+// buffer k, and the host only blocks in adsb_feed_pop() for results that are not ready yet.  Two buffers may be
+// in flight (the ctx alternates between two result sets).
+//   parity mode (carry = 0, the reference's behaviour): every buffer is its own reference buffer; the last 240
+//     offsets of each are never looked at (adsb.rs:98); offsets are buffer-relative.
+//   carry mode (carry = 1): the last 240 samples of the stream so far are kept ON THE DEVICE and copied, device
+//     to device, in front of the next buffer before it is demodulated: the chunked stream decodes exactly like one
+//     long buffer (frames straddling two buffers are found); offsets are absolute stream positions.
+// Staging slot layout (samples): [ head: up to 240 carried samples | the buffer ], the buffer's copy lands behind
+// the carried samples and the demodulated region starts at a multiple of 8 samples (16-byte alignment).
+struct adsb_feed {
+    adsb_ctx *c = nullptr;
+    adsb_feed_cfg cfg{};
+    uint32_t bps = 2;
+    hipStream_t copy = nullptr;
+    char *dev[2] = {nullptr, nullptr};
+    hipEvent_t h2d_done[2] = {nullptr, nullptr}, kern_done[2] = {nullptr, nullptr};
+    // results of the launch from staging slot k are complete and visible to the copy engine (a default event: its
+    // record releases to system scope, unlike the ctx's device-scope events)
+    bool kern_pending[2] = {false, false};
+    std::vector<char *> ring;
+    std::vector<hipEvent_t> ring_done; // H2D out of that ring slot has completed
+    std::vector<char> ring_busy;
+    uint32_t ring_next = 0;
+    int acquired = -1;
+    uint64_t pushed = 0, popped = 0; // buffers
+    uint64_t consumed = 0;           // samples pushed so far
+    size_t prev_start = 0, prev_len = 0; // demodulated region of the previous buffer's slot (samples)
+    struct Entry {
+        bool launched = false;
+        uint32_t set = 0;
+        uint64_t first_sample = 0; // stream position of the buffer's first own sample
+    } q[2];
+    adsbk::Header *hdr_host = nullptr;
+};
+
+extern "C" void adsb_feed_close(adsb_feed *f)
+{
+    if (!f) return;
+    if (f->c) (void)hipSetDevice(f->c->cfg.device);
+    if (f->copy) (void)hipStreamSynchronize(f->copy);
+    if (f->c && f->c->stream) (void)hipStreamSynchronize(f->c->stream);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipFree(f->dev[k]);
+        if (f->h2d_done[k]) (void)hipEventDestroy(f->h2d_done[k]);
+        if (f->kern_done[k]) (void)hipEventDestroy(f->kern_done[k]);
+    }
+    for (char *p : f->ring) (void)hipHostFree(p);
+    for (hipEvent_t e : f->ring_done) if (e) (void)hipEventDestroy(e);
+    if (f->hdr_host) (void)hipHostFree(f->hdr_host);
+    if (f->copy) (void)hipStreamDestroy(f->copy);
+    if (f->c) { (void)adsb_set_stream_base(f->c, 0); }
+    delete f;
+}
+
+extern "C" int adsb_feed_open(adsb_ctx *c, const adsb_feed_cfg *cfg, adsb_feed **out)
+{
+    if (!c || !cfg || !out || cfg->max_chunk == 0) return ADSB_E_ARG;
+    *out = nullptr;
+    // one launch covers the buffer, in carry mode with the 240 carried samples in front of it
+    if (cfg->max_chunk + (cfg->carry ? (size_t)kWindow : 0) > c->cfg.max_samples) return ADSB_E_CAPACITY;
+    if (c->cfg.max_channels < 1) return ADSB_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    adsb_feed *f = new (std::nothrow) adsb_feed();
+    if (!f) return ADSB_E_NOMEM;
+    f->c = c;
+    f->cfg = *cfg;
+    if (f->cfg.ring_slots < 2) f->cfg.ring_slots = 3;
+    f->bps = c->bps;
+    bool ok = hipStreamCreateWithFlags(&f->copy, hipStreamNonBlocking) == hipSuccess;
+    const size_t slot_bytes = (cfg->max_chunk + (size_t)kWindow + 8) * f->bps;
+    for (int k = 0; k < 2 && ok; ++k)
+        ok = hipMalloc((void **)&f->dev[k], slot_bytes) == hipSuccess &&
+             hipEventCreateWithFlags(&f->h2d_done[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&f->kern_done[k], hipEventDisableTiming) == hipSuccess;
+    for (uint32_t k = 0; k < f->cfg.ring_slots && ok; ++k) {
+        char *p = nullptr;
+        hipEvent_t e = nullptr;
+        ok = hipHostMalloc((void **)&p, cfg->max_chunk * f->bps, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (p) f->ring.push_back(p);
+        if (e) f->ring_done.push_back(e);
+        f->ring_busy.push_back(0);
+    }
+    ok = ok && hipHostMalloc((void **)&f->hdr_host, sizeof(adsbk::Header), hipHostMallocDefault) == hipSuccess;
+    if (!ok) { adsb_feed_close(f); return ADSB_E_NOMEM; }
+    *out = f;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_feed_in_flight(const adsb_feed *f) { return f ? (int)(f->pushed - f->popped) : ADSB_E_ARG; }
+
+static int feed_ring_slot(adsb_feed *f, uint32_t *slot)
+{
+    const uint32_t r = f->ring_next;
+    if (f->ring_busy[r]) { // the DMA out of this slot must have finished before the host overwrites it
+        HIPCHK(hipEventSynchronize(f->ring_done[r]));
+        f->ring_busy[r] = 0;
+    }
+    *slot = r;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_feed_acquire(adsb_feed *f, void **host_slot)
+{
+    if (!f || !host_slot) return ADSB_E_ARG;
+    if (f->acquired >= 0) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(f->c->cfg.device));
+    uint32_t r = 0;
+    int rc = feed_ring_slot(f, &r);
+    if (rc != ADSB_OK) return rc;
+    f->acquired = (int)r;
+    *host_slot = f->ring[r];
+    return ADSB_OK;
+}
+
+extern "C" int adsb_feed_push(adsb_feed *f, const void *iq_host, size_t n)
+{
+    if (!f || n == 0 || n > f->cfg.max_chunk) return ADSB_E_ARG;
+    if (!iq_host && f->acquired < 0) return ADSB_E_ARG;
+    if (f->pushed - f->popped >= 2) return ADSB_E_STATE; // two buffers in flight: pop first
+    // parity mode: the reference panics on a buffer shorter than 240 samples (adsb.rs:98); nothing is consumed
+    if (!f->cfg.carry && n < (size_t)kWindow) return ADSB_E_SHORT;
+    adsb_ctx *c = f->c;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    uint32_t r = 0;
+    if (f->acquired >= 0) {
+        r = (uint32_t)f->acquired;
+        if (iq_host && iq_host != f->ring[r]) std::memcpy(f->ring[r], iq_host, n * f->bps);
+        f->acquired = -1;
+    } else {
+        int rc = feed_ring_slot(f, &r);
+        if (rc != ADSB_OK) return rc;
+        std::memcpy(f->ring[r], iq_host, n * f->bps);
+    }
+    f->ring_next = (r + 1) % (uint32_t)f->ring.size();
+
+    const uint32_t s = (uint32_t)(f->pushed & 1u);
+    const size_t tail = (f->cfg.carry && f->pushed) ? std::min<size_t>(kWindow, f->prev_len) : 0;
+    const size_t start = ((size_t)kWindow - tail) / 8 * 8; // 16-byte aligned start of the demodulated region
+    const size_t len = tail + n;
+    // this staging slot was last read by the launch two buffers ago
+    if (f->kern_pending[s]) HIPCHK(hipStreamWaitEvent(f->copy, f->kern_done[s], 0));
+    HIPCHK(hipMemcpyAsync(f->dev[s] + (start + tail) * f->bps, f->ring[r], n * f->bps, hipMemcpyHostToDevice, f->copy));
+    HIPCHK(hipEventRecord(f->ring_done[r], f->copy));
+    f->ring_busy[r] = 1;
+    if (tail) // the last `tail` samples of what the previous launch saw, device to device (its H2D is earlier on this stream)
+        HIPCHK(hipMemcpyAsync(f->dev[s] + start * f->bps, f->dev[s ^ 1u] + (f->prev_start + f->prev_len - tail) * f->bps,
+                              tail * f->bps, hipMemcpyDeviceToDevice, f->copy));
+    HIPCHK(hipEventRecord(f->h2d_done[s], f->copy));
+
+    adsb_feed::Entry &e = f->q[s];
+    e.first_sample = f->consumed;
+    e.launched = false;
+    if (len >= (size_t)kWindow) {
+        HIPCHK(hipStreamWaitEvent(c->stream, f->h2d_done[s], 0));
+        // after a pop of an older launch the ctx may "view" that launch: the next enqueue starts from the newest state
+        const uint64_t base = f->cfg.carry ? f->consumed - tail : 0;
+        int rc = adsb_set_stream_base(c, base);
+        if (rc == ADSB_OK) rc = adsb_demod_device_async(c, f->dev[s] + start * f->bps, 1, len, len);
+        if (rc != ADSB_OK) return rc;
+        e.launched = true;
+        e.set = c->last;
+        HIPCHK(hipEventRecord(f->kern_done[s], c->aux)); // THIS launch's kernels and results (not the stream's tail)
+        f->kern_pending[s] = true;
+    }
+    f->prev_start = start;
+    f->prev_len = len;
+    f->consumed += n;
+    f->pushed++;
+    return ADSB_OK;
+}
+
+extern "C" int adsb_feed_pop(adsb_feed *f, adsb_frame *out, size_t max_out, size_t *n_out, uint32_t *flags,
+                             uint64_t *first_sample)
+{
+    if (!f || !n_out || (!out && max_out)) return ADSB_E_ARG;
+    *n_out = 0;
+    if (flags) *flags = 0;
+    if (f->popped == f->pushed) return ADSB_E_STATE;
+    adsb_ctx *c = f->c;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    adsb_feed::Entry &e = f->q[f->popped & 1u];
+    if (first_sample) *first_sample = e.first_sample;
+    f->popped++;
+    if (!e.launched) return ADSB_OK; // (carry mode, fewer than 240 samples so far: nothing decodable yet)
+    adsb_ctx::ResultSet &r = c->rs[e.set];
+    // results travel on the copy stream, behind this launch's ordering pass only -- not behind the kernels of the
+    // buffer pushed after it, which share the ctx stream
+    HIPCHK(hipStreamWaitEvent(f->copy, f->kern_done[(f->popped - 1) & 1u], 0));
+    HIPCHK(hipMemcpyAsync(f->hdr_host, r.hdr, sizeof(adsbk::Header), hipMemcpyDeviceToHost, f->copy));
+    HIPCHK(hipStreamSynchronize(f->copy));
+    if (f->hdr_host->retry) { // slot-pool overflow (pathological input): the slow, fully synchronous path
+        const uint32_t newest = c->last;
+        view_launch(c, e.set);
+        size_t got = 0;
+        uint32_t fl = 0;
+        int rc = adsb_fetch(c, out, max_out, &got, nullptr, nullptr, &fl);
+        view_launch(c, newest);
+        if (rc != ADSB_OK) return rc;
+        *n_out = got;
+        if (flags) *flags = fl;
+        return ADSB_OK;
+    }
+    uint64_t n = f->hdr_host->n_out;
+    uint32_t fl = f->hdr_host->flags;
+    if (n > max_out) { n = max_out; fl |= ADSB_FLAG_TRUNCATED; }
+    if (n) {
+        HIPCHK(hipMemcpyAsync(out, r.li.out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, f->copy));
+        HIPCHK(hipStreamSynchronize(f->copy));
+    }
+    *n_out = (size_t)n;
+    if (flags) *flags = fl;
     return ADSB_OK;
 }

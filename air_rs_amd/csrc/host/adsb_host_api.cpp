@@ -72,7 +72,7 @@ extern "C" size_t adsb_packet_display(const uint8_t bytes[14], const char *time_
 template <typename T>
 static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_len, adsb_frame *frames,
                         size_t max_frames, size_t *n_frames, uint64_t *n_buffers, char *text,
-                        size_t text_cap, size_t *text_len, bool carry_over)
+                        size_t text_cap, size_t *text_len, bool carry_over, bool send_tail = false)
 {
     const Complex<T> *src = static_cast<const Complex<T> *>(data);
     std::vector<Complex<T>> all(src, src + n);
@@ -83,11 +83,11 @@ static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_
     Thread2Stats st;
     std::string printed;
 
-    std::thread t1([tx = std::move(raw.first), d = std::move(all), chunk_len]() mutable {
-        playback_thread<T>(std::move(tx), std::move(d), chunk_len, false);
+    std::thread t1([tx = std::move(raw.first), d = std::move(all), chunk_len, send_tail]() mutable {
+        playback_thread<T>(std::move(tx), std::move(d), chunk_len, false, send_tail);
     });
     std::thread t2([&, rx = std::move(raw.second), tx = std::move(msgs.first)]() mutable {
-        st = process_sdr_data_thread<T>(ctx, std::move(rx), std::move(tx), &log, chunk_len + 240, carry_over);
+        st = process_sdr_data_thread<T>(ctx, std::move(rx), std::move(tx), &log, chunk_len + 240, carry_over, chunk_len);
     });
     std::thread t3([&, rx = std::move(msgs.second)]() mutable {
         while (auto packet = rx.recv()) printed += "\n" + packet->to_string("") + "\n"; // adsb.rs:156-158
@@ -107,7 +107,7 @@ static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_
 
 static int pipeline(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples, size_t chunk_len,
                     adsb_frame *frames, size_t max_frames, size_t *n_frames, uint64_t *n_buffers, char *text,
-                    size_t text_cap, size_t *text_len, bool carry_over)
+                    size_t text_cap, size_t *text_len, bool carry_over, bool send_tail = false)
 {
     if (!ctx || !data || chunk_len == 0) return ADSB_E_ARG;
     // the context copies n * (its own bytes per sample) out of every chunk: the caller's idea of the sample
@@ -115,10 +115,10 @@ static int pipeline(adsb_ctx *ctx, int sample_type, const void *data, size_t n_s
     if (sample_type != adsb_sample_type(ctx)) return ADSB_E_ARG;
     if (sample_type == ADSB_SAMPLE_I16)
         return run_pipeline<int16_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
-                                     text, text_cap, text_len, carry_over);
+                                     text, text_cap, text_len, carry_over, send_tail);
     if (sample_type == ADSB_SAMPLE_I8)
         return run_pipeline<int8_t>(ctx, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers,
-                                    text, text_cap, text_len, carry_over);
+                                    text, text_cap, text_len, carry_over, send_tail);
     return ADSB_E_ARG;
 }
 
@@ -137,6 +137,50 @@ extern "C" int adsb_pipeline_playback_carry(adsb_ctx *ctx, int sample_type, cons
 {
     return pipeline(ctx, sample_type, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers, nullptr,
                     0, nullptr, true);
+}
+
+extern "C" int adsb_pipeline_run(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples, size_t chunk_len,
+                                 uint32_t flags, adsb_frame *frames, size_t max_frames, size_t *n_frames,
+                                 uint64_t *n_buffers, char *text, size_t text_cap, size_t *text_len)
+{
+    if (flags & ~(ADSB_REPLAY_CARRY | ADSB_REPLAY_SEND_TAIL)) return ADSB_E_ARG;
+    return pipeline(ctx, sample_type, data, n_samples, chunk_len, frames, max_frames, n_frames, n_buffers, text,
+                    text_cap, text_len, (flags & ADSB_REPLAY_CARRY) != 0, (flags & ADSB_REPLAY_SEND_TAIL) != 0);
+}
+
+extern "C" int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples);
+extern "C" int adsb_load_u8(const char *path, int8_t **data, size_t *n_samples);
+
+// `air_rs adsb -p FILE -m stream` (main.rs:19-23 -> launch_adsb, adsb.rs:126-173) with thread 2 on the GPU: the file
+// is read whole (utils.rs:22-43), cut into chunk_len-sample buffers by the playback thread and printed by the
+// stream thread.
+extern "C" int adsb_replay_file(adsb_ctx *ctx, const char *path, int file_format, size_t chunk_len, uint32_t flags,
+                                adsb_frame *frames, size_t max_frames, size_t *n_frames, uint64_t *n_buffers,
+                                uint64_t *n_samples, char *text, size_t text_cap, size_t *text_len)
+{
+    if (!ctx || !path) return ADSB_E_ARG;
+    void *data = nullptr;
+    size_t n = 0;
+    int st_type, rc;
+    if (file_format == ADSB_FILE_C16) {
+        int16_t *d = nullptr;
+        rc = adsb_load_c16(path, &d, &n);
+        data = d;
+        st_type = ADSB_SAMPLE_I16;
+    } else if (file_format == ADSB_FILE_U8) {
+        int8_t *d = nullptr;
+        rc = adsb_load_u8(path, &d, &n);
+        data = d;
+        st_type = ADSB_SAMPLE_I8;
+    } else {
+        return ADSB_E_ARG;
+    }
+    if (rc != ADSB_OK) return rc;
+    if (n_samples) *n_samples = n;
+    rc = adsb_pipeline_run(ctx, st_type, data, n, chunk_len, flags, frames, max_frames, n_frames, n_buffers, text,
+                           text_cap, text_len);
+    std::free(data);
+    return rc;
 }
 
 extern "C" int adsb_load_c16(const char *path, int16_t **data, size_t *n_samples)

@@ -24,10 +24,11 @@ bool load_data(const std::string &filename, IqBufI16 &out, std::string &err);
 bool save_data(const IqBufI16 &data, const std::string &filename, std::string &err);
 
 // adsb.rs:75-89: 20 000-sample buffers, `while i < len - 20000` (the tail is never sent), then
-// drop(tx).  pace=true keeps the reference's 5 ms sleep per buffer.
+// drop(tx).  pace=true keeps the reference's 5 ms sleep per buffer.  send_tail=true (NOT reference behaviour,
+// SURVEY 8f-1) also sends what the reference's strict `<` leaves behind: the last full or partial chunk.
 template <typename T>
 void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>> data,
-                     size_t chunk_len = 20000, bool pace = false);
+                     size_t chunk_len = 20000, bool pace = false, bool send_tail = false);
 
 // adsb.rs:92-122: for every received buffer, demodulate and send one AdsbPacket per frame, in
 // ascending offset order; return when either channel closes; drop(tx) at the end.
@@ -36,8 +37,12 @@ void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>>
 //
 // carry_over (NOT reference behaviour, off by default): the reference never looks at
 // the last 240 offsets of a buffer, so frames straddling two buffers are lost.  With
-// carry_over the last 240 samples of each buffer are prepended to the next one, which makes the
-// chunked stream decode exactly like one long buffer.
+// carry_over the last 240 samples of the stream stay on the device and are put in front of the next buffer
+// there, which makes the chunked stream decode exactly like one long buffer.
+// Either way the buffers go through the streaming front end of the C ABI (adsb_feed_*: pinned host ring,
+// asynchronous DMA overlapped with the previous buffer's kernels, two buffers in flight); packets leave in
+// buffer order, ascending offset inside a buffer, one buffer behind the newest one received.
+// max_chunk: the largest buffer the source may send (the ctx needs max_samples >= max_chunk + 240).
 struct Thread2Stats {
     uint64_t buffers = 0, frames = 0, truncated_buffers = 0;
     int last_error = ADSB_OK; // first non-OK code returned by the C ABI, if any
@@ -46,6 +51,6 @@ template <typename T>
 Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex<T>>> rx,
                                      Sender<AdsbPacket> tx,
                                      std::vector<adsb_frame> *frames_log = nullptr,
-                                     size_t max_frames = 65536, bool carry_over = false);
+                                     size_t max_frames = 65536, bool carry_over = false, size_t max_chunk = 0);
 
 } // namespace air_rs_amd

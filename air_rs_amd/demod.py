@@ -5,6 +5,7 @@ example ``torch.Tensor.data_ptr()``) carry HBM-resident ones.  Frames come back 
 structured array with the adsb_frame layout.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -312,6 +313,34 @@ class AdsbDemod:
         txt = text.value.decode() if want_text else None
         return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value, txt
 
+    def pipeline_run(self, data, chunk_len=20000, carry=False, send_tail=False, max_frames=1 << 20, want_text=True):
+        """adsb_pipeline_run: playback thread -> GPU thread 2 (streaming front end) -> stream-mode text."""
+        data = np.ascontiguousarray(data, dtype=self._np_dtype)
+        frames = np.zeros(max_frames, dtype=FRAME_DTYPE)
+        n_frames, n_buf, text_len = C.c_size_t(), C.c_uint64(), C.c_size_t()
+        cap = 1 << 26 if want_text else 0
+        text = C.create_string_buffer(cap) if want_text else None
+        flags = (L.ADSB_REPLAY_CARRY if carry else 0) | (L.ADSB_REPLAY_SEND_TAIL if send_tail else 0)
+        L.check(self._lib.adsb_pipeline_run(self._h, self.sample_type, data.ctypes.data, data.shape[0], chunk_len, flags,
+                                            frames.ctypes.data_as(C.POINTER(L.AdsbFrame)), max_frames, C.byref(n_frames),
+                                            C.byref(n_buf), text, cap, C.byref(text_len)), "adsb_pipeline_run")
+        return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value, (text.value.decode() if want_text else None)
+
+    def replay_file(self, path, file_format=None, chunk_len=20000, carry=False, send_tail=False, max_frames=1 << 20):
+        """adsb_replay_file: `.c16` (ctx i16) or raw rtl_sdr u8 (ctx i8) file -> (frames, n_buffers, n_samples, text)."""
+        if file_format is None:
+            file_format = L.ADSB_FILE_C16 if self.sample_type == L.ADSB_SAMPLE_I16 else L.ADSB_FILE_U8
+        frames = np.zeros(max_frames, dtype=FRAME_DTYPE)
+        n_frames, n_buf, n_samp, text_len = C.c_size_t(), C.c_uint64(), C.c_uint64(), C.c_size_t()
+        cap = 1 << 26
+        text = C.create_string_buffer(cap)
+        flags = (L.ADSB_REPLAY_CARRY if carry else 0) | (L.ADSB_REPLAY_SEND_TAIL if send_tail else 0)
+        L.check(self._lib.adsb_replay_file(self._h, os.fsencode(path), file_format, chunk_len, flags,
+                                           frames.ctypes.data_as(C.POINTER(L.AdsbFrame)), max_frames, C.byref(n_frames),
+                                           C.byref(n_buf), C.byref(n_samp), text, cap, C.byref(text_len)),
+                "adsb_replay_file")
+        return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value, n_samp.value, text.value.decode()
+
     def pipeline_playback_carry(self, data, chunk_len=20000, max_frames=1 << 20):
         """Like pipeline_playback but thread 2 carries the last 240 samples over (not reference behaviour)."""
         data = np.ascontiguousarray(data, dtype=self._np_dtype)
@@ -322,6 +351,56 @@ class AdsbDemod:
                                                        max_frames, C.byref(n_frames), C.byref(n_buf)),
                 "adsb_pipeline_playback_carry")
         return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value
+
+
+class Feed:
+    """Streaming front end (adsb_feed_*): push host buffers, pop their frames in order; two may be in flight."""
+
+    def __init__(self, dem, max_chunk, carry=False, ring_slots=3):
+        self._lib, self._dem = dem._lib, dem
+        cfg = L.AdsbFeedCfg(int(max_chunk), 1 if carry else 0, int(ring_slots))
+        h = C.c_void_p()
+        L.check(self._lib.adsb_feed_open(dem.handle, C.byref(cfg), C.byref(h)), "adsb_feed_open")
+        self._h, self.max_chunk, self.carry = h, int(max_chunk), bool(carry)
+
+    def close(self):
+        if self._h:
+            self._lib.adsb_feed_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def in_flight(self):
+        return self._lib.adsb_feed_in_flight(self._h)
+
+    def push(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=self._dem._np_dtype)
+        n = iq.shape[0] if iq.ndim == 2 else iq.size // 2
+        L.check(self._lib.adsb_feed_push(self._h, iq.ctypes.data, n), "adsb_feed_push")
+
+    def acquire(self):
+        """A pinned ring slot as a numpy array of shape (max_chunk, 2) to fill in place; then push_acquired(n)."""
+        p = C.c_void_p()
+        L.check(self._lib.adsb_feed_acquire(self._h, C.byref(p)), "adsb_feed_acquire")
+        itemsize = np.dtype(self._dem._np_dtype).itemsize
+        buf = (C.c_char * (self.max_chunk * 2 * itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=self._dem._np_dtype).reshape(self.max_chunk, 2)
+
+    def push_acquired(self, n):
+        L.check(self._lib.adsb_feed_push(self._h, None, int(n)), "adsb_feed_push")
+
+    def pop(self, max_out=None):
+        cap = self._dem.max_out if max_out is None else max_out
+        out = np.zeros(max(cap, 1), dtype=FRAME_DTYPE)
+        n_out, flags, first = C.c_size_t(), C.c_uint32(), C.c_uint64()
+        L.check(self._lib.adsb_feed_pop(self._h, out.ctypes.data_as(C.POINTER(L.AdsbFrame)), cap, C.byref(n_out),
+                                        C.byref(flags), C.byref(first)), "adsb_feed_pop")
+        return out[:n_out.value].copy(), flags.value, first.value
 
 
 def packet_new(frame_bytes):

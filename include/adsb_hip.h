@@ -159,6 +159,43 @@ int adsb_set_stream_base(adsb_ctx *ctx, uint64_t first_sample_index);
 int adsb_stream_wait_results(adsb_ctx *ctx, void *stream);
 
 /*
+ * ---- streaming front end -------------------------------------------------------------
+ * The reference's thread 2 receives one Vec per recv() (src/adsb.rs:95) from the SDR reader (adsb.rs:54-73) or
+ * the playback thread (adsb.rs:75-89) and treats each as an island.  A feed takes the same sequence of host
+ * buffers and keeps the GPU busy across them: each buffer goes through a pinned host ring to one of two device
+ * staging slots by asynchronous DMA on a copy stream, overlapped with the previous buffer's kernels; up to two
+ * buffers are in flight, results come back in order from adsb_feed_pop().  The ctx must have been created with
+ * max_samples >= max_chunk (+ 240 in carry mode; cfg.host_staging is not needed) and must not be used for other
+ * launches while the feed is open.
+ *   carry = 0 (default, the reference's behaviour): every buffer is its own reference buffer: offsets
+ *     0 .. n-241 of each are examined, frames straddling two buffers are lost (adsb.rs:98); frame
+ *     offsets are buffer-relative (*first_sample of adsb_feed_pop says where the buffer began in the stream); a
+ *     buffer shorter than 240 samples makes adsb_feed_push return ADSB_E_SHORT (the reference panics).
+ *   carry = 1 (NOT reference behaviour): the last 240 samples seen so far stay on the device and are copied,
+ *     device to device, in front of the next buffer: the chunked stream decodes exactly like one long buffer of
+ *     the same samples; frame offsets are absolute stream positions.
+ */
+typedef struct adsb_feed adsb_feed;
+typedef struct adsb_feed_cfg {
+    size_t   max_chunk;   /* largest buffer (samples) that will be pushed                          */
+    uint32_t carry;       /* 0 = per-buffer semantics (reference), 1 = carry the 240-sample tail    */
+    uint32_t ring_slots;  /* pinned host buffers of max_chunk samples (0: 3)                        */
+} adsb_feed_cfg;
+int adsb_feed_open(adsb_ctx *ctx, const adsb_feed_cfg *cfg, adsb_feed **out_feed);
+/* Optional zero-copy producer path: a pinned ring slot (max_chunk samples) to fill in place; hand it over with
+ * adsb_feed_push(feed, NULL, n).  Blocks only if the DMA out of that slot has not finished yet. */
+int adsb_feed_acquire(adsb_feed *feed, void **host_slot);
+/* Enqueues one buffer (copied into the ring unless it was acquired) and returns without waiting for the GPU.
+ * ADSB_E_STATE when two buffers are already in flight (pop first). */
+int adsb_feed_push(adsb_feed *feed, const void *iq_host, size_t n_samples);
+/* Waits for the OLDEST buffer in flight and returns its frames in ascending offset order; *first_sample
+ * (optional) = stream position of that buffer's first sample.  ADSB_E_STATE when nothing is in flight. */
+int adsb_feed_pop(adsb_feed *feed, adsb_frame *out, size_t max_out, size_t *n_out, uint32_t *flags,
+                  uint64_t *first_sample);
+int adsb_feed_in_flight(const adsb_feed *feed); /* 0, 1 or 2 */
+void adsb_feed_close(adsb_feed *feed);
+
+/*
  * On-device field decode of the last launch's frame list: what AdsbPacket::new
  * computes per frame (src/adsb/packet.rs:25-49, src/adsb/msgs.rs:70-102,150-201), as one 32-byte
  * record per frame, in frame order.  Lets the host wrapper only wrap when output volumes are large.

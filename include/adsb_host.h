@@ -65,12 +65,38 @@ int adsb_pipeline_playback(adsb_ctx *ctx, int sample_type, const void *data, siz
  * behaviour): the last 240 samples of every buffer are prepended to the next, so frames straddling
  * two buffers -- which the reference loses (adsb.rs:95-98) -- are decoded, and the chunked stream
  * yields exactly what one long buffer of the samples actually sent would.  The ctx must have been
- * created for max_samples >= chunk_len + 240.
+ * created for max_samples >= chunk_len + 240.  (Both entry points run thread 2 on the streaming front end,
+ * adsb_feed_*: pinned ring, asynchronous DMA, the 240-sample tail kept on the device.)
  */
 int adsb_pipeline_playback_carry(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples,
                                  size_t chunk_len, adsb_frame *frames, size_t max_frames,
                                  size_t *n_frames, uint64_t *n_buffers);
 
+
+/*
+ * The general form of the two entry points above, and the replay entry: what
+ * `air_rs adsb -p FILE -m stream` does (main.rs:19-23 -> launch_adsb, adsb.rs:126-173) with thread 2 on the GPU.
+ *   flags: ADSB_REPLAY_CARRY      thread 2 carries the last 240 samples over (not reference behaviour)
+ *          ADSB_REPLAY_SEND_TAIL  the playback thread also sends the last full or partial chunk, which
+ *                                 adsb.rs:77's strict `<` never sends (not reference behaviour)
+ *          0 reproduces the reference: per-buffer demodulation, tail dropped.
+ * adsb_replay_file reads the whole file like utils.rs:22-43 (ADSB_FILE_C16: raw little-endian i16 I,Q pairs, the
+ * reference's `.c16`; the ctx must be ADSB_SAMPLE_I16) or as a raw rtl_sdr capture (ADSB_FILE_U8: unsigned bytes
+ * re-centred as x - 128; the ctx must be ADSB_SAMPLE_I8; not a format the reference reads), cuts it into
+ * chunk_len-sample buffers (20000 in the reference) and returns the frames (offsets absolute in the file) and the
+ * stream-mode text ("\n{packet}\n" per packet, adsb.rs:157, "Processed Time" values blanked).  The ctx must have
+ * been created for max_samples >= chunk_len + 240.
+ */
+#define ADSB_REPLAY_CARRY 0x1u
+#define ADSB_REPLAY_SEND_TAIL 0x2u
+#define ADSB_FILE_C16 0
+#define ADSB_FILE_U8 1
+int adsb_pipeline_run(adsb_ctx *ctx, int sample_type, const void *data, size_t n_samples, size_t chunk_len,
+                      uint32_t flags, adsb_frame *frames, size_t max_frames, size_t *n_frames, uint64_t *n_buffers,
+                      char *text, size_t text_cap, size_t *text_len);
+int adsb_replay_file(adsb_ctx *ctx, const char *path, int file_format, size_t chunk_len, uint32_t flags,
+                     adsb_frame *frames, size_t max_frames, size_t *n_frames, uint64_t *n_buffers,
+                     uint64_t *n_samples, char *text, size_t text_cap, size_t *text_len);
 
 /* ---- behind the channel: tracker + CPR ------------------------------------------- */
 
