@@ -1,15 +1,23 @@
 #!/bin/bash
 # GPU box helper: the round's measured artefacts in one call: parity, default bench line (+cpu baseline),
-# rocprofv3 kernel stats, PMC passes, the streaming kernel's bench line and the 16 GiB configuration.
+# rocprofv3 kernel stats of the same command, PMC passes (i8 and CS16), the 16 GiB / CS16 / 64-channel configurations.
+# Everything lands under gpurun_out/ (r_* files); copy what is to be judged into profiles/.
 set -o pipefail
 mkdir -p gpurun_out
 tools/gpu/bench_and_profile.sh || exit 1
 cp gpurun_out/bench.json gpurun_out/r_bench.json
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r_kernel_stats.csv
 tools/gpu/pmc_passes.sh > gpurun_out/pmc_out.txt 2>&1 || { tail -20 gpurun_out/pmc_out.txt; exit 1; }
-cp gpurun_out/pmc/summary.json gpurun_out/r_pmc_summary.json
-python bench.py --steps 30 --warmup 3 --no-cpu-baseline --kernel stream > gpurun_out/r_bench_stream.json 2>gpurun_out/r_bench_stream.err || exit 1
+cp gpurun_out/pmc/summary.json gpurun_out/r_pmc_summary_i8.json
+BENCH_ARGS="--sample-type i16" tools/gpu/pmc_passes.sh > gpurun_out/pmc_out_i16.txt 2>&1 || { tail -20 gpurun_out/pmc_out_i16.txt; exit 1; }
+cp gpurun_out/pmc/summary.json gpurun_out/r_pmc_summary_i16.json
+python bench.py --steps 30 --warmup 3 --no-cpu-baseline --sample-type i16 > gpurun_out/r_bench_cs16.json 2>gpurun_out/r_bench_cs16.err || exit 1
 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --samples 8589934592 > gpurun_out/r_bench_16g.json 2>gpurun_out/r_bench_16g.err || exit 1
-python bench.py --steps 10 --warmup 2 --no-cpu-baseline --samples 8589934592 --kernel stream > gpurun_out/r_bench_16g_stream.json 2>gpurun_out/r_bench_16g_stream.err || exit 1
-for f in r_bench r_bench_stream r_bench_16g r_bench_16g_stream; do python3 -c "
-import json; d=json.load(open('gpurun_out/$f.json')); r=d['roofline']; print('$f', r['kernel'], 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'GB/s', r['achieved'], 'frac', r['frac'], 'ceil', r['read_ceiling_gbps'])"; done
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline --samples 8589934592 --sample-type i16 > gpurun_out/r_bench_cs16_16g.json 2>gpurun_out/r_bench_cs16_16g.err || exit 1
+python bench.py --steps 30 --warmup 3 --no-cpu-baseline --channels 64 > gpurun_out/r_bench_64ch.json 2>gpurun_out/r_bench_64ch.err || exit 1
+rm -rf gpurun_out/prof16 && mkdir -p gpurun_out/prof16
+TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof16 -o stats -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --samples 8589934592 > gpurun_out/prof16_bench.json 2> gpurun_out/prof16.err
+f=$(find gpurun_out/prof16 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r_kernel_stats_16g.csv
+for f in r_bench r_bench_cs16 r_bench_16g r_bench_cs16_16g r_bench_64ch; do python3 -c "
+import json; d=json.load(open('gpurun_out/$f.json')); r=d['roofline']; fp=r.get('fused_pass',{})
+print('$f', r['kernel'], 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'GB/s', r['achieved'], 'frac', r['frac'], 'ceil', r['read_ceiling_gbps'], 'fused_ms', fp.get('kernel_ms'), 'fused_frac', fp.get('frac'))"; done
