@@ -696,8 +696,11 @@ __device__ __forceinline__ void magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIt
 // tile in ~10 % more VALU instructions (loop-carried registers, SGPR spills) and come out 7 % slower: in-kernel cycle
 // stamps (tools/gpu/tile_stamps.py) show the SIMDs VALU-saturated while any three of the four slots compute, so
 // filling the gaps buys nothing -- the instruction count is what bounds this kernel.
-template <int ST, int MAGMODE>
-__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4))) void demod_tiles(DemodArgs p)
+// FUSED_ONLY (bench.py's roofline.fused_pass, adsb_debug_fused_pass_only): the same code stopped after the fused
+// magnitude + preamble/DF17 pass -- survivors are counted, nothing is sliced or CRC-checked, no frames come out.  Its
+// own kernel (demod_tiles_fused_pass) so that profilers list it apart from the product kernel.
+template <int ST, int MAGMODE, bool FUSED_ONLY>
+__device__ __forceinline__ void demod_tile_body(const DemodArgs &p)
 {
     typedef Lds<ST> L;
     typedef TileCfg<ST> TC; // tile length of this sample type
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
 #if ADSB_ABL_PHASES < 3
         if (total != 0x7FFFFFFFu) total = 0; // survivors are counted (phase 2 stays alive) but not decoded
 #endif
-        if (p.fused_pass_only) total = 0; // bench.py's "fused magnitude+preamble pass" figure (one scalar select)
+        if (FUSED_ONLY && total != 0x7FFFFFFFu) total = 0; // (never that value: keeps phase 2's count alive)
         const bool dense = total > (uint32_t)kSparseCap;
         u32x4 cw = {0, 0, 0, 0};
         uint32_t cnt = 0, my_first = 0;
@@ -890,6 +893,16 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
+#define ADSB_TILE_LAUNCH_BOUNDS __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4)))
+template <int ST, int MAGMODE> __global__ ADSB_TILE_LAUNCH_BOUNDS void demod_tiles(DemodArgs p)
+{
+    demod_tile_body<ST, MAGMODE, false>(p);
+}
+template <int ST, int MAGMODE> __global__ ADSB_TILE_LAUNCH_BOUNDS void demod_tiles_fused_pass(DemodArgs p)
+{
+    demod_tile_body<ST, MAGMODE, true>(p);
+}
+
 // Timing events ride on the dispatch itself (hipExtLaunchKernelGGL): no extra barrier packets in
 // the stream, so the timed loop of bench.py is the same command stream as an untimed one.
 template <int ST>
@@ -897,10 +910,19 @@ static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &
                                   hipEvent_t e0, hipEvent_t e1)
 {
     dim3 grid(grid_x), block(kThreads);
+    if (ST == ADSB_SAMPLE_I16) mag_mode = 0; // the CS16 magnitude chain does not depend on the converter's rounding
+    if (a.fused_pass_only) {
+        switch (mag_mode) {
+        case 0: hipExtLaunchKernelGGL((demod_tiles_fused_pass<ST, 0>), grid, block, 0, s, e0, e1, 0, a); break;
+        case 1: hipExtLaunchKernelGGL((demod_tiles_fused_pass<ST, ST == ADSB_SAMPLE_I8 ? 1 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
+        default: hipExtLaunchKernelGGL((demod_tiles_fused_pass<ST, ST == ADSB_SAMPLE_I8 ? 2 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
+        }
+        return hipGetLastError();
+    }
     switch (mag_mode) {
     case 0: hipExtLaunchKernelGGL((demod_tiles<ST, 0>), grid, block, 0, s, e0, e1, 0, a); break;
-    case 1: hipExtLaunchKernelGGL((demod_tiles<ST, 1>), grid, block, 0, s, e0, e1, 0, a); break;
-    default: hipExtLaunchKernelGGL((demod_tiles<ST, 2>), grid, block, 0, s, e0, e1, 0, a); break;
+    case 1: hipExtLaunchKernelGGL((demod_tiles<ST, ST == ADSB_SAMPLE_I8 ? 1 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
+    default: hipExtLaunchKernelGGL((demod_tiles<ST, ST == ADSB_SAMPLE_I8 ? 2 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
     }
     return hipGetLastError();
 }

@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--hipcc", default=os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
     ap.add_argument("-D", action="append", default=[])
     ap.add_argument("--out")
+    ap.add_argument("--weight", action="append", default=[], metavar="PHASE=W",
+                    help="how often a wave executes that phase's instructions per tile (default 1): gives the "
+                         "'per tile' column, to be checked against SQ_INSTS_VALU per wave")
+    ap.add_argument("--note", action="append", default=[], help="free text appended to the report")
     a = ap.parse_args()
 
     srcdir = os.path.dirname(os.path.abspath(a.src))
@@ -116,22 +120,33 @@ def main():
         ops_by_phase[phase][op] += 1
         n_total += 1
 
+    weights = {}
+    for kv in a.weight:
+        k, v = kv.rsplit("=", 1)
+        weights[k] = float(v)
     out = []
     w = out.append
     w(f"# ISA issue-slot count: {a.kernel}")
     w(f"# source {os.path.relpath(a.src)}  defines {a.D}  (static instruction counts from hipcc -S, gfx950)")
     w("# slots = VALU instructions x 1 + transcendentals x 2 (4-cycle issue units per wave64 instruction)")
-    w(f"{'phase':34s} {'valu':>6s} {'cmp':>5s} {'trans':>6s} {'lane':>5s} {'SLOTS':>7s} | {'salu':>5s} {'lds':>5s} {'vmem':>5s} {'branch':>6s} {'wait':>5s}")
+    w(f"{'phase':38s} {'valu':>6s} {'cmp':>5s} {'trans':>6s} {'lane':>5s} {'SLOTS':>7s} | {'salu':>5s} {'lds':>5s} {'vmem':>5s} {'branch':>6s} {'wait':>5s} | {'x/tile':>6s} {'instr/tile':>10s} {'slots/tile':>10s}")
     tot = collections.Counter()
+    dyn_i = dyn_s = 0.0
     for phase in sorted(counts):
         c = counts[phase]
-        slots = c["valu"] + c["valu_cmp"] + c["valu_lane"] + 2 * c["valu_trans"]
-        w(f"{phase:34s} {c['valu']:6d} {c['valu_cmp']:5d} {c['valu_trans']:6d} {c['valu_lane']:5d} {slots:7d} | "
-          f"{c['salu']:5d} {c['lds']:5d} {c['vmem']:5d} {c['branch']:6d} {c['wait']:5d}")
+        n_valu = c["valu"] + c["valu_cmp"] + c["valu_lane"] + c["valu_trans"]
+        slots = n_valu + c["valu_trans"]
+        wt = weights.get(phase, 1.0)
+        dyn_i += wt * n_valu
+        dyn_s += wt * slots
+        w(f"{phase:38s} {c['valu']:6d} {c['valu_cmp']:5d} {c['valu_trans']:6d} {c['valu_lane']:5d} {slots:7d} | "
+          f"{c['salu']:5d} {c['lds']:5d} {c['vmem']:5d} {c['branch']:6d} {c['wait']:5d} | {wt:6.2f} {wt * n_valu:10.0f} {wt * slots:10.0f}")
         tot.update(c)
         tot["slots"] += slots
-    w(f"{'TOTAL (static)':34s} {tot['valu']:6d} {tot['valu_cmp']:5d} {tot['valu_trans']:6d} {tot['valu_lane']:5d} {tot['slots']:7d} | "
-      f"{tot['salu']:5d} {tot['lds']:5d} {tot['vmem']:5d} {tot['branch']:6d} {tot['wait']:5d}")
+    w(f"{'TOTAL':38s} {tot['valu']:6d} {tot['valu_cmp']:5d} {tot['valu_trans']:6d} {tot['valu_lane']:5d} {tot['slots']:7d} | "
+      f"{tot['salu']:5d} {tot['lds']:5d} {tot['vmem']:5d} {tot['branch']:6d} {tot['wait']:5d} | {'':6s} {dyn_i:10.0f} {dyn_s:10.0f}")
+    for n in a.note:
+        w("# " + n)
     w("")
     for phase in sorted(ops_by_phase):
         top = ", ".join(f"{op} {n}" for op, n in ops_by_phase[phase].most_common(14))
