@@ -125,6 +125,7 @@ PROTOTYPES = {
     "adsb_set_stream_base": (C.c_int, [C.c_void_p, C.c_uint64]),
     "adsb_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "adsb_timing_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_uint32)]),
+    "adsb_timing_read3": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_uint32)]),
     "adsb_time_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, _P(C.c_double)]),
     "adsb_debug_magnitudes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "adsb_debug_mag_mode": (C.c_int, [C.c_void_p]),

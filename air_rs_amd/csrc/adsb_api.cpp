@@ -96,7 +96,7 @@ struct adsb_ctx {
 
     // timing
     int timing = 0;                 // 0 off; N: events on every N-th launch
-    hipEvent_t ev[kTimingRing][4] = {};
+    hipEvent_t ev[kTimingRing][6] = {}; // scan kernel, ordering pass, decode kernel: start/end each
     bool ev_made = false;
     uint32_t ev_count = 0;
 };
@@ -425,9 +425,12 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
         }
         ev = c->ev[c->ev_count % kTimingRing];
     }
-    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode,
-                               demod_args(c, r, i % 3u, 0, c->last_tiles, true), ev ? ev[0] : nullptr,
-                               ev ? ev[1] : nullptr));
+    const adsbk::DemodArgs da = demod_args(c, r, i % 3u, 0, c->last_tiles, true);
+    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, da, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
+    // second kernel: slice + CRC of the survivors the scan kernel listed (the experimental streaming kernel decodes
+    // in place and marks its tiles decoded; measurement mode stops after the scan)
+    if (!c->fused_pass_only)
+        HIPCHK(adsbk::launch_decode(c->stream, c->cfg.sample_type, c->mag_mode, da, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr));
     if (c->own_aux) {
         HIPCHK(hipEventRecord(r.k_done, c->stream));
         HIPCHK(hipStreamWaitEvent(c->aux, r.k_done, 0));
@@ -495,6 +498,8 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
         if ((e = hipMemsetAsync(&r.hdr->alloc, 0, sizeof(unsigned long long), c->stream)) != hipSuccess ||
             (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode,
                                      demod_args(c, r, grp_set, t0, t1 - t0, false))) != hipSuccess ||
+            (e = adsbk::launch_decode(c->stream, c->cfg.sample_type, c->mag_mode,
+                                      demod_args(c, r, grp_set, t0, t1 - t0, false))) != hipSuccess ||
             (e = adsbk::launch_gather(c->stream, compact_args(c, r, grp_set, -1, t0, t1 - t0, true))) != hipSuccess)
             rc = (int)e;
         t0 = t1;
@@ -726,23 +731,35 @@ extern "C" int adsb_timing_enable(adsb_ctx *c, int on)
     return ADSB_OK;
 }
 
+static int timing_read(adsb_ctx *c, double *demod_ms, double *order_ms, double *decode_ms, uint32_t *n_launches);
 extern "C" int adsb_timing_read(adsb_ctx *c, double *demod_ms, double *order_ms, uint32_t *n_launches)
+{
+    return timing_read(c, demod_ms, order_ms, nullptr, n_launches);
+}
+extern "C" int adsb_timing_read3(adsb_ctx *c, double *scan_ms, double *decode_ms, double *order_ms, uint32_t *n_launches)
+{
+    return timing_read(c, scan_ms, order_ms, decode_ms, n_launches);
+}
+static int timing_read(adsb_ctx *c, double *demod_ms, double *order_ms, double *decode_ms, uint32_t *n_launches)
 {
     if (!c) return ADSB_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->aux));
     uint32_t n = std::min<uint32_t>(c->ev_count, kTimingRing);
-    double a = 0, b = 0;
+    double a = 0, b = 0, d = 0;
     for (uint32_t k = 0; k < n; ++k) {
-        float x = 0, y = 0;
+        float x = 0, y = 0, z = 0;
         HIPCHK(hipEventElapsedTime(&x, c->ev[k][0], c->ev[k][1]));
         HIPCHK(hipEventElapsedTime(&y, c->ev[k][2], c->ev[k][3]));
+        if (!c->fused_pass_only) HIPCHK(hipEventElapsedTime(&z, c->ev[k][4], c->ev[k][5]));
         a += x;
         b += y;
+        d += z;
     }
     if (demod_ms) *demod_ms = n ? a / n : 0.0;
     if (order_ms) *order_ms = n ? b / n : 0.0;
+    if (decode_ms) *decode_ms = n ? d / n : 0.0;
     if (n_launches) *n_launches = n;
     c->ev_count = 0;
     return ADSB_OK;

@@ -50,10 +50,10 @@ constexpr int kGrp2Shards = 16;
 
 // One entry per tile, written unconditionally by the demod kernel.
 struct Seg {
-    uint32_t base;   // first temp slot of this tile, kNoBase if the slot store was full
-    uint32_t cand;   // offsets that passed the preamble+DF17 gate (slots reserved)
-    uint32_t valid;  // of those, frames that passed CRC / single-bit repair
-    uint32_t pad;
+    uint32_t base;    // first temp slot of this tile, kNoBase if the slot store was full
+    uint32_t cand;    // offsets that passed the preamble+DF17 gate (slots reserved; the scan kernel writes each survivor's offset there)
+    uint32_t valid;   // of those, frames that passed CRC / single-bit repair (written by the decode kernel)
+    uint32_t decoded; // 1: `valid` is already final when the scan kernel ends (a tile without slots, counted in place)
 };
 
 // Device-resident result header (adsb_result_device).
@@ -120,6 +120,9 @@ hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]
 // e0/e1: optional events recorded at the start / end of the dispatch itself (nullptr: none)
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// second kernel of a launch: PPM slice + CRC-24 + repair of the survivors the scan kernel listed (same DemodArgs)
+hipError_t launch_decode(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
+                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nullptr,
                          hipEvent_t e1 = nullptr);
 

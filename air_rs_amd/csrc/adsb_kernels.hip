@@ -28,6 +28,8 @@
 //     the reference's mpsc channel would deliver them in.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "adsb_kernels.h"
 #include "adsb_synth.h"
 
@@ -328,12 +330,11 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
 // Lane l slices frame byte l (magnitudes off+16+16l .. +15, demod.rs:97-101).  The 24-byte record
 // {offset, bytes[14], status, fixed_bit} is written to `rec` (LDS); returns (on every lane) whether the
 // frame is valid (CRC matched, or one data bit repaired: crc.rs:49-65).
-template <int ST, bool NIBBLES = false>
-__device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *mag, const uint32_t *syn, unsigned char *rec,
-                                                 const bool have, const uint32_t off, const uint64_t sample0,
-                                                 const uint32_t l, const uint32_t lane, const uint32_t *nib = nullptr)
+// The PPM slice of one frame byte (demod.rs:92-131 + 180-201 in closed form): bit (7-k) = m[16 lb + 2k] > m[16 lb + 2k + 1]
+// over the magnitudes off+16+16*lb .. +15 of the tile in LDS; strict, a tie gives 0.
+template <int ST>
+__device__ __forceinline__ uint32_t slice_byte(const typename MagT<ST>::type *mag, const uint32_t off, const uint32_t lb)
 {
-    const uint32_t lb = l < 14 ? l : 13;
     uint32_t byte = 0;
     if (ST == ADSB_SAMPLE_I16) {
         const typename MagT<ST>::type *mp = mag + off + 16 + 16 * lb;
@@ -357,6 +358,16 @@ __device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *
             byte |= ((z >> (8 + 2 * k)) & 0xFFu) | (z >> (25 + 2 * k));
         }
     }
+    return byte;
+}
+
+template <int ST, bool NIBBLES = false>
+__device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *mag, const uint32_t *syn, unsigned char *rec,
+                                                 const bool have, const uint32_t off, const uint64_t sample0,
+                                                 const uint32_t l, const uint32_t lane, const uint32_t *nib = nullptr)
+{
+    const uint32_t lb = l < 14 ? l : 13;
+    uint32_t byte = slice_byte<ST>(mag, off, lb);
     // syndrome = XOR of table entries of the set bits, over the 14 bytes
     uint32_t s = 0;
     const uint32_t *sy = syn + 8 * lb;
@@ -690,17 +701,15 @@ __device__ __forceinline__ void magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIt
 // co-resident workgroups.  Per tile:
 //   phase 1  17 x 16 bytes per lane of raw IQ, all in flight at once, become magnitudes in LDS;      ... barrier
 //   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase);                                ... barrier
-//   phase 3  survivors are sliced, CRC-checked, repaired and written to the tile's slots.
+//   phase 3  every survivor gets a frame slot, its offset and its 14 sliced bytes; CRC-24, repair and ordering are
+//            finish_candidates' (below).
 // Measured alternatives: persistent workgroups drawing tiles from per-XCD ticket counters with
 // the next tile's loads issued before phase 3 (no slot ever waits for the dispatcher or for its samples) run the same
 // tile in ~10 % more VALU instructions (loop-carried registers, SGPR spills) and come out 7 % slower: in-kernel cycle
 // stamps (tools/gpu/tile_stamps.py) show the SIMDs VALU-saturated while any three of the four slots compute, so
 // filling the gaps buys nothing -- the instruction count is what bounds this kernel.
-// FUSED_ONLY (bench.py's roofline.fused_pass, adsb_debug_fused_pass_only): the same code stopped after the fused
-// magnitude + preamble/DF17 pass -- survivors are counted, nothing is sliced or CRC-checked, no frames come out.  Its
-// own kernel (demod_tiles_fused_pass) so that profilers list it apart from the product kernel.
-template <int ST, int MAGMODE, bool FUSED_ONLY>
-__device__ __forceinline__ void demod_tile_body(const DemodArgs &p)
+template <int ST, int MAGMODE>
+__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4))) void demod_tiles(DemodArgs p)
 {
     typedef Lds<ST> L;
     typedef TileCfg<ST> TC; // tile length of this sample type
@@ -769,13 +778,16 @@ __device__ __forceinline__ void demod_tile_body(const DemodArgs &p)
         __syncthreads();
         TSTAMP(4); // barrier
 
-        // [phase:3 list, slots, records]
-        // ---- phase 3: ordered candidate list, PPM slice, CRC-24, single-bit repair --------------
+        // [phase:3 hand-over: survivor offsets to the frame slots]
+        // ---- phase 3: PPM slice of the gate survivors; the CRC stage is a kernel of its own --------------------
+        // Every survivor gets a frame slot, its absolute offset and its 14 sliced bytes (the magnitudes are here, in
+        // LDS).  CRC-24, repair, ordering inside the tile and the valid-frame count are finish_candidates' work, one
+        // LANE per survivor instead of sixteen.  (With the whole decode in this kernel a tile's 33 KB of LDS were
+        // held through a latency-bound epilogue: 19 % of the kernel time for 13 % of its instructions.)
         uint32_t total = misc[12];
 #if ADSB_ABL_PHASES < 3
-        if (total != 0x7FFFFFFFu) total = 0; // survivors are counted (phase 2 stays alive) but not decoded
+        if (total != 0x7FFFFFFFu) total = 0; // survivors are counted (phase 2 stays alive) but not handed over
 #endif
-        if (FUSED_ONLY && total != 0x7FFFFFFFu) total = 0; // (never that value: keeps phase 2's count alive)
         const bool dense = total > (uint32_t)kSparseCap;
         u32x4 cw = {0, 0, 0, 0};
         uint32_t cnt = 0, my_first = 0;
@@ -806,65 +818,72 @@ __device__ __forceinline__ void demod_tile_body(const DemodArgs &p)
 
         // Frame slots: the tile's own fixed region when the survivors fit (no atomics), otherwise
         // one allocation from the shared pool.  In the usual case (a handful of survivors) every thread knows
-        // the base without asking tid 0, and the list is complete since the barrier above: no barrier (c).
+        // the base without asking tid 0, and the list is complete since the barrier above: no further barrier.
         const bool simple = !dense && total <= kQuota;
-        if (tid == 0) {
-            uint32_t b = tile * kQuota;
-            if (total > kQuota) {
-                const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
-                b = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
-            }
-            misc[9] = b;
-        }
-        // (misc[9] becomes visible at the next barrier)
-
-        for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
-            if (dense && cnt) {
-                uint32_t idx = my_first;
-                const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t bits = words[k];
-                    while (bits) {
-                        const uint32_t b = __builtin_ctz(bits);
-                        bits &= bits - 1;
-                        if (idx >= chunk && idx < chunk + kListCap)
-                            list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
-                        ++idx;
-                    }
-                }
-            }
-            if (!simple) __syncthreads();
-            const uint32_t base_slot = simple ? tile * kQuota : misc[9];
-            const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
-            const uint32_t g = tid >> 4, l = tid & 15;
+        const uint64_t abs0 = sample0 + p.offset_base; // absolute offset of this tile's offset 0
+        uint32_t base_slot = tile * kQuota;
+        // 16-lane groups slice one survivor each, one lane per frame byte, and store offset + 14 raw bytes (no CRC
+        // verdict yet) into the survivor's slot: 16 survivors per workgroup round
+        const uint32_t g = tid >> 4, l = tid & 15;
+        auto slice_round = [&](uint32_t slot0, uint32_t ncl) {
             for (uint32_t r = 0; r < ncl; r += 16) {
-                if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a candidate
+                if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a survivor
                 const uint32_t ci = r + g;
                 const bool have = ci < ncl; // uniform within the 16-lane group
                 const uint32_t off = have ? list[ci] : 0u;
-                // sparse path: the list is unordered; the slot is the candidate's rank among the listed
-                // offsets (total <= kSparseCap = 64 = 16 lanes x 4)
-                uint32_t slot = ci;
-                if (!dense) {
-                    uint32_t below = 0;
-#pragma unroll
-                    for (int k = 0; k < kSparseCap / 16; ++k) {
-                        const uint32_t j = l + 16 * k;
-                        const uint32_t e = j < total ? (uint32_t)list[j] : 0xFFFFFFFFu;
-                        below += e < off ? 1u : 0u;
-                    }
-                    slot = row16_sum(below);
-                }
-                unsigned char *rec = res + g * 24;
-                const bool valid = decode_candidate<ST>(mag, syn, rec, have, off, sample0 + p.offset_base, l, lane);
-                if (valid && l == 0) atomicAdd(&misc[8], 1u);
-                if (have && base_slot != kNoBase && l < 6) {
-                    uint32_t *dst = reinterpret_cast<uint32_t *>(p.slots + (size_t)base_slot + chunk + slot);
-                    dst[l] = reinterpret_cast<const uint32_t *>(rec)[l];
+                const uint32_t byte = slice_byte<ST>(mag, off, l < 14 ? l : 13);
+                if (have) {
+                    unsigned char *rec = reinterpret_cast<unsigned char *>(p.slots + (size_t)slot0 + ci);
+                    const uint64_t o64 = abs0 + off;
+                    if (l < 14) rec[8 + l] = (unsigned char)byte;
+                    else reinterpret_cast<uint32_t *>(rec)[l - 14] = l == 14 ? (uint32_t)o64 : (uint32_t)(o64 >> 32);
                 }
             }
+        };
+        if (simple) {
+            slice_round(base_slot, total); // unordered list (finish_candidates ranks it): survivor j -> slot j
+        } else {
+            if (tid == 0) {
+                const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+                misc[9] = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
+            }
             __syncthreads();
+            base_slot = misc[9];
+            for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+                if (dense && cnt) {
+                    uint32_t idx = my_first;
+                    const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t bits = words[k];
+                        while (bits) {
+                            const uint32_t b = __builtin_ctz(bits);
+                            bits &= bits - 1;
+                            if (idx >= chunk && idx < chunk + kListCap)
+                                list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
+                            ++idx;
+                        }
+                    }
+                }
+                __syncthreads();
+                const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
+                if (base_slot != kNoBase) {
+                    slice_round(base_slot + chunk, ncl); // (ordered when dense; 33..64 survivors: unordered like the simple case)
+                } else {
+                    // The slot store is full (pathological input: SURVEY F8).  The host re-plans from exact counts,
+                    // so this tile's survivors are decoded HERE, from the magnitudes in LDS, only to be counted.
+                    for (uint32_t r = 0; r < ncl; r += 16) {
+                        if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a candidate
+                        const uint32_t ci = r + g;
+                        const bool have = ci < ncl; // uniform within the 16-lane group
+                        const uint32_t off = have ? list[ci] : 0u;
+                        unsigned char *rec = res + g * 24;
+                        const bool valid = decode_candidate<ST>(mag, syn, rec, have, off, abs0, l, lane);
+                        if (valid && l == 0) atomicAdd(&misc[8], 1u);
+                    }
+                }
+                __syncthreads();
+            }
         }
         TSTAMP(5); // phase 3
 #if ADSB_TILE_STAMPS
@@ -875,32 +894,220 @@ __device__ __forceinline__ void demod_tile_body(const DemodArgs &p)
             if (wave) dst[6] = ts_seg[8]; // wave 3's load wait is wave 0's: its slot carries the s_memtime stamp
         }
 #endif
-        // (total == 0: nothing was added to misc[8] since tid 0 cleared it before the phase-1 barrier)
+        // Seg::valid is written by the decode kernel, except for a tile that lost its slots (counted above)
         if (tid == 0) {
             Seg e;
-            e.base = simple ? tile * kQuota : misc[9];
+            e.base = base_slot;
             e.cand = total;
             e.valid = misc[8];
-            e.pad = 0;
-            p.seg[tile] = e;
-            if (e.valid && p.count_groups) {
-                atomicAdd(&p.grp1[tile >> kGrpShift], e.valid);
-                atomicAdd(&p.grp2[(tile >> (2 * kGrpShift)) * kGrp2Shards + ((tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
-            }
+            e.decoded = base_slot == kNoBase ? 1u : 0u;
+            p.seg[tile] = e; // (finish_candidates sums the groups' counters, this tile's count included)
         }
     }
     // [phase:end]
     if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
-#define ADSB_TILE_LAUNCH_BOUNDS __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4)))
-template <int ST, int MAGMODE> __global__ ADSB_TILE_LAUNCH_BOUNDS void demod_tiles(DemodArgs p)
+// ---- CRC-24 + single-bit repair of the sliced survivors (demod.rs:71-81; crc.rs:10-65) --------------------------
+// Byte-wise table of the Mode-S CRC-24 (generator 0x1FFF409, MSB first, init 0, no final XOR: crc.rs:10-40):
+// kCrcTab[v] = (v * x^24) mod G.  crc' = (crc << 8) ^ kCrcTab[(crc >> 16) ^ byte] over the 11 data bytes.
+struct CrcTable {
+    uint32_t v[256];
+};
+constexpr CrcTable make_crc_table()
 {
-    demod_tile_body<ST, MAGMODE, false>(p);
+    CrcTable t{};
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t r = i << 16;
+        for (int k = 0; k < 8; ++k) {
+            r <<= 1;
+            if (r & 0x1000000u) r ^= 0x1FFF409u;
+        }
+        t.v[i] = r & 0xFFFFFFu;
+    }
+    return t;
 }
-template <int ST, int MAGMODE> __global__ ADSB_TILE_LAUNCH_BOUNDS void demod_tiles_fused_pass(DemodArgs p)
+__constant__ CrcTable kCrcTab = make_crc_table();
+// The 88 data-bit syndromes sorted, (syndrome << 7) | bit index, padded to 128 entries: the single-bit repair of
+// crc.rs:49-65 (at most one of the 88 distinct non-zero values matches) as a 7-step binary search.
+struct SynSorted {
+    uint32_t v[128];
+};
+constexpr SynSorted make_syn_sorted()
 {
-    demod_tile_body<ST, MAGMODE, true>(p);
+    SynSorted t{};
+    SynTable sy = make_syn();
+    for (int j = 0; j < 128; ++j) t.v[j] = j < 88 ? ((sy.v[j] << 7) | (uint32_t)j) : 0xFFFFFFFFu;
+    for (int i = 1; i < 128; ++i) { // insertion sort (constant evaluation)
+        uint32_t x = t.v[i];
+        int k = i - 1;
+        while (k >= 0 && t.v[k] > x) {
+            t.v[k + 1] = t.v[k];
+            --k;
+        }
+        t.v[k + 1] = x;
+    }
+    return t;
+}
+__constant__ SynSorted kSynSorted = make_syn_sorted();
+
+// finish_candidates: the second kernel of a launch.  The scan kernel (demod_tiles) left, per tile, `Seg{base, cand}` and,
+// in the slots base .. base+cand-1, every gate survivor's absolute offset and 14 sliced bytes (unordered when cand <=
+// kSparseCap, ascending otherwise).  One workgroup of 16 waves takes one GROUP of 64 consecutive tiles (the unit of the
+// gather pass's first-level counters), four tiles per wave, one LANE per survivor: the lane loads its 24-byte record,
+// runs the byte-wise CRC-24 over the 11 data bytes (1 KB table in LDS), compares with the received CRC; a non-zero
+// syndrome is looked up among the 88 data-bit syndromes (sorted, binary search) and that bit flipped (crc.rs:49-65: a
+// flip in the CRC field itself never matches); the lane's rank among the tile's survivors by offset (a readlane loop:
+// <= 64 per tile unless the tile is dense, and then they are already in order) is where the finished record {offset,
+// bytes, status, fixed_bit} goes, so that the gather pass finds every tile's slots in offset order.  The tile's
+// valid-frame count goes to its Seg; the workgroup sums its 64 tiles in LDS and writes the group's counter with a
+// plain store and ONE atomic to the second-level counter (4 arrivals per address).  Per-tile atomics, as the in-tile
+// decoder used to issue them spread over the whole scan, cost 70 us here, where 16 384 of them arrive within a few
+// microseconds on 320 addresses (measured: 0.085 ms with, 0.013 ms without them).
+// All loads of a wave's four tiles are issued before the first is used: two memory round trips per wave.
+constexpr int kFinishWaves = 16; // waves per workgroup: 64 tiles = one first-level group
+constexpr int kFinishTPW = 4;    // tiles per wave
+static_assert(kFinishWaves * kFinishTPW == (1 << kGrpShift), "one workgroup per first-level group");
+
+// One chunk (<= 64 survivors, one per lane) of one tile: w = the lane's record as loaded.  Returns the number of
+// valid frames of the chunk (wave-uniform).
+__device__ __forceinline__ uint32_t finish_chunk(const DemodArgs &p, const Seg &e, uint32_t chunk, uint32_t ncl,
+                                                 uint32_t (&w)[6], const uint32_t *crc_tab, const uint32_t *syn_sorted,
+                                                 uint32_t lane)
+{
+    const bool have = lane < ncl;
+    // frame byte i is record byte 8 + i: dword 2 + (i >> 2), byte (i & 3)
+    uint32_t crc = 0;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const uint32_t b = (w[2 + (i >> 2)] >> (8 * (i & 3))) & 0xFFu;
+        crc = ((crc << 8) ^ crc_tab[((crc >> 16) ^ b) & 0xFFu]) & 0xFFFFFFu;
+    }
+    const uint32_t rx = ((w[4] >> 24) << 16) | ((w[5] & 0xFFu) << 8) | ((w[5] >> 8) & 0xFFu); // frame bytes 11, 12, 13
+    const uint32_t sm = crc ^ rx;
+    uint32_t pos = 0; // binary search: first entry whose syndrome is >= sm
+#pragma unroll
+    for (int step = 64; step >= 1; step >>= 1)
+        pos += ((syn_sorted[pos + step - 1] >> 7) < sm) ? (uint32_t)step : 0u;
+    const uint32_t hit = syn_sorted[pos];
+    const bool found = sm != 0 && (hit >> 7) == sm;
+    const bool valid = have && (sm == 0 || found);
+    uint32_t status = 0xFFu, fixed = 0xFFu;
+    if (valid) {
+        status = sm == 0 ? 0u : 1u;
+        if (sm != 0) {
+            fixed = hit & 0x7Fu; // data bit 0..87, MSB first
+            const uint32_t bi = 8u + (fixed >> 3);                 // record byte of that bit
+            const uint32_t flip = (0x80u >> (fixed & 7u)) << (8u * (bi & 3u));
+            const uint32_t wi = bi >> 2;                           // 2, 3 or 4
+            w[2] ^= wi == 2 ? flip : 0u;
+            w[3] ^= wi == 3 ? flip : 0u;
+            w[4] ^= wi == 4 ? flip : 0u;
+        }
+    }
+    w[5] = (w[5] & 0xFFFFu) | (status << 16) | (fixed << 24);
+    // where the record goes: its rank by offset among the tile's survivors
+    uint32_t slot = lane;
+    if (e.cand <= (uint32_t)kSparseCap) { // unordered, and one chunk holds them all
+        uint32_t below = 0;
+        for (uint32_t k = 0; k < ncl; ++k) {
+            const uint32_t ok_lo = (uint32_t)__builtin_amdgcn_readlane((int)w[0], (int)k);
+            const uint32_t ok_hi = (uint32_t)__builtin_amdgcn_readlane((int)w[1], (int)k);
+            below += (ok_hi < w[1] || (ok_hi == w[1] && ok_lo < w[0])) ? 1u : 0u;
+        }
+        slot = below;
+    }
+    if (have) {
+        uint2 *dst = reinterpret_cast<uint2 *>(p.slots + (size_t)e.base + chunk + slot);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dst[k] = make_uint2(w[2 * k], w[2 * k + 1]);
+    }
+    return (uint32_t)__builtin_popcountll(__ballot(valid));
+}
+
+__global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs p)
+{
+    __shared__ uint32_t crc_tab[256];
+    __shared__ uint32_t syn_sorted[128];
+    __shared__ uint32_t counts[1 << kGrpShift];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 256) crc_tab[threadIdx.x] = kCrcTab.v[threadIdx.x];
+    else if (threadIdx.x < 384) syn_sorted[threadIdx.x - 256] = kSynSorted.v[threadIdx.x - 256];
+    else if (threadIdx.x < 384 + (1 << kGrpShift)) counts[threadIdx.x - 384] = 0;
+    __syncthreads();
+
+    const uint32_t group = (p.tile_first >> kGrpShift) + blockIdx.x;
+    const uint32_t t_end = p.tile_first + p.tile_count;
+    // ---- both memory round trips of this wave's tiles up front ---------------------------------------------------
+    Seg e[kFinishTPW];
+    bool live[kFinishTPW];
+#pragma unroll
+    for (int i = 0; i < kFinishTPW; ++i) {
+        const uint32_t tile = (group << kGrpShift) + wave * kFinishTPW + i;
+        const bool in_range = tile >= p.tile_first && tile < t_end; // (wave-uniform)
+        e[i].base = kNoBase; e[i].cand = 0; e[i].valid = 0; e[i].decoded = 1;
+        if (in_range) e[i] = p.seg[tile];
+        live[i] = in_range && e[i].cand != 0 && e[i].base != kNoBase && !e[i].decoded;
+    }
+    uint32_t w[kFinishTPW][6];
+#pragma unroll
+    for (int i = 0; i < kFinishTPW; ++i) {
+        w[i][0] = w[i][1] = 0xFFFFFFFFu;
+        w[i][2] = w[i][3] = w[i][4] = w[i][5] = 0;
+        if (live[i] && lane < e[i].cand) { // (first chunk; every record of a chunk is read before any is written)
+            const uint2 *src = reinterpret_cast<const uint2 *>(p.slots + (size_t)e[i].base + lane);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint2 v = src[k];
+                w[i][2 * k] = v.x;
+                w[i][2 * k + 1] = v.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kFinishTPW; ++i) {
+        const uint32_t tile = (group << kGrpShift) + wave * kFinishTPW + i;
+        uint32_t n_good = e[i].valid; // (a tile the scan kernel had to decode itself keeps its count)
+        if (live[i]) {
+            n_good = finish_chunk(p, e[i], 0, e[i].cand < 64u ? e[i].cand : 64u, w[i], crc_tab, syn_sorted, lane);
+            for (uint32_t chunk = 64; chunk < e[i].cand; chunk += 64) { // dense tile (pathological input): in order already
+                const uint32_t ncl = (e[i].cand - chunk) < 64u ? (e[i].cand - chunk) : 64u;
+                uint32_t x[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
+                if (lane < ncl) {
+                    const uint2 *src = reinterpret_cast<const uint2 *>(p.slots + (size_t)e[i].base + chunk + lane);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint2 v = src[k];
+                        x[2 * k] = v.x;
+                        x[2 * k + 1] = v.y;
+                    }
+                }
+                n_good += finish_chunk(p, e[i], chunk, ncl, x, crc_tab, syn_sorted, lane);
+            }
+            if (lane == 0) p.seg[tile].valid = n_good;
+        }
+        if (lane == 0) counts[wave * kFinishTPW + i] = n_good;
+    }
+    __syncthreads();
+    if (wave == 0 && p.count_groups) { // the group's counter: plain store; second level: one atomic per group
+        uint32_t v = counts[lane];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        if (lane == 0) {
+            p.grp1[group] = v;
+            if (v) atomicAdd(&p.grp2[(group >> kGrpShift) * kGrp2Shards + (group & (kGrp2Shards - 1))], v);
+        }
+    }
+}
+
+hipError_t launch_decode(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a, hipEvent_t e0, hipEvent_t e1)
+{
+    (void)mag_mode;
+    (void)sample_type;
+    if (a.tile_count == 0) return hipSuccess;
+    const uint32_t g0 = a.tile_first >> kGrpShift, g1 = (a.tile_first + a.tile_count - 1) >> kGrpShift;
+    hipExtLaunchKernelGGL(finish_candidates, dim3(g1 - g0 + 1), dim3(kFinishWaves * 64), 0, s, e0, e1, 0, a);
+    return hipGetLastError();
 }
 
 // Timing events ride on the dispatch itself (hipExtLaunchKernelGGL): no extra barrier packets in
@@ -911,14 +1118,6 @@ static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &
 {
     dim3 grid(grid_x), block(kThreads);
     if (ST == ADSB_SAMPLE_I16) mag_mode = 0; // the CS16 magnitude chain does not depend on the converter's rounding
-    if (a.fused_pass_only) {
-        switch (mag_mode) {
-        case 0: hipExtLaunchKernelGGL((demod_tiles_fused_pass<ST, 0>), grid, block, 0, s, e0, e1, 0, a); break;
-        case 1: hipExtLaunchKernelGGL((demod_tiles_fused_pass<ST, ST == ADSB_SAMPLE_I8 ? 1 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
-        default: hipExtLaunchKernelGGL((demod_tiles_fused_pass<ST, ST == ADSB_SAMPLE_I8 ? 2 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
-        }
-        return hipGetLastError();
-    }
     switch (mag_mode) {
     case 0: hipExtLaunchKernelGGL((demod_tiles<ST, 0>), grid, block, 0, s, e0, e1, 0, a); break;
     case 1: hipExtLaunchKernelGGL((demod_tiles<ST, ST == ADSB_SAMPLE_I8 ? 1 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
@@ -1016,7 +1215,7 @@ __global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
     const uint32_t t0 = a.tile_first + (blockIdx.x * 4 + wave) * 4;
     if (t0 >= t_end) return;
     Seg mine;
-    mine.base = kNoBase; mine.cand = 0; mine.valid = 0; mine.pad = 0;
+    mine.base = kNoBase; mine.cand = 0; mine.valid = 0; mine.decoded = 0;
     if (lane < 4 && t0 + lane < t_end) mine = a.seg[t0 + lane];
     // the tiles' own records and the counts the position is summed from are independent loads: issued together
     uint32_t pos0 = a.out_start ? 0u : tile_prefix(a, t0, lane);

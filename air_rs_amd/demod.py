@@ -279,6 +279,12 @@ class AdsbDemod:
                 "adsb_timing_read")
         return a.value, b.value, n.value
 
+    def timing_read3(self):
+        """(scan_ms, decode_ms, order_ms, n_launches): the three kernels of a launch, mean per timed launch."""
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
+        L.check(self._lib.adsb_timing_read3(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)), "adsb_timing_read3")
+        return a.value, b.value, c.value, n.value
+
     def time_read_ceiling(self, dev_ptr, nbytes, iters=10):
         ms = C.c_double()
         L.check(self._lib.adsb_time_read_ceiling(self._h, dev_ptr, nbytes, iters, C.byref(ms)),

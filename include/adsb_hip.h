@@ -269,6 +269,11 @@ int adsb_sample_type(const adsb_ctx *ctx);
  * (at most the 512 most recent launches) and clears the log.
  */
 int adsb_timing_enable(adsb_ctx *ctx, int on);
+/* The three kernels of a launch separately: the scan kernel (demod_tiles: magnitude + preamble/DF17 gate over every
+ * sample -- the kernel that reads the IQ bytes), the decode kernel (decode_candidates: PPM slice + CRC-24 of the
+ * gate survivors) and the ordering pass (gather_tiles).  adsb_timing_read reports the first and the last. */
+int adsb_timing_read3(adsb_ctx *ctx, double *scan_ms_mean, double *decode_ms_mean, double *order_ms_mean,
+                      uint32_t *n_launches);
 int adsb_timing_read(adsb_ctx *ctx, double *demod_ms_mean, double *order_ms_mean,
                      uint32_t *n_launches);
 /* Pure-read HBM ceiling on this device: streams `bytes` from `buf_dev` `iters` times with 16-byte
@@ -281,9 +286,9 @@ int adsb_debug_magnitudes(adsb_ctx *ctx, const void *iq_host, size_t n_samples,
 /* How v_cvt_pk_u8_f32 was found to round on this device: 0 truncates, 1 truncates under
  * MODE.fp_round = toward-zero, 2 rounds to nearest (kernel subtracts 0.5 first). */
 int adsb_debug_mag_mode(adsb_ctx *ctx);
-/* Measurement only (bench.py's roofline.fused_pass): with on != 0 the following launches run the fused
- * magnitude + preamble/DF17 pass of demod_tiles and stop there -- gate survivors are counted but not sliced or
- * CRC-checked, so NO frames come out.  on = 0 restores the full path. */
+/* Measurement only: with on != 0 the following launches run the scan kernel (the fused magnitude +
+ * preamble/DF17 pass) and the ordering pass but not the decode kernel -- gate survivors are listed but not sliced
+ * or CRC-checked, so NO frames come out.  on = 0 restores the full path. */
 int adsb_debug_fused_pass_only(adsb_ctx *ctx, int on);
 /* Which kernel the context launches: 0 = demod_tiles, one workgroup per tile -- the only kernel of the product
  * build, for i8 and i16 alike.  1 = the experimental streaming kernel (one persistent workgroup per CU,

@@ -377,12 +377,8 @@ __device__ __forceinline__ void stream_decode_role(const DemodArgs &p, unsigned 
             e.base = base;
             e.cand = total;
             e.valid = misc[L::kValid + k3];
-            e.pad = 0;
-            p.seg[tile] = e;
-            if (e.valid && p.count_groups) {
-                atomicAdd(&p.grp1[tile >> kGrpShift], e.valid);
-                atomicAdd(&p.grp2[(tile >> (2 * kGrpShift)) * kGrp2Shards + ((tile >> kGrpShift) & (kGrp2Shards - 1))], e.valid);
-            }
+            e.decoded = 1; // this kernel slices and CRC-checks in place: the decode kernel skips its tiles
+            p.seg[tile] = e; // (finish_candidates, which runs after every tile kernel, sums the group counters)
             misc[L::kValid + k3] = 0;
             misc[L::kCount + k3] = 0;
         }
