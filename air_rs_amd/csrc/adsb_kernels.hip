@@ -28,8 +28,6 @@
 //     the reference's mpsc channel would deliver them in.
 #include <hip/hip_ext.h>
 
-#include <cstdlib>
-
 #include "adsb_kernels.h"
 #include "adsb_synth.h"
 
