@@ -303,7 +303,7 @@ __device__ __forceinline__ uint32_t pair_at_cold(const uint32_t *ra, const uint3
     }
 }
 
-// [phase:3 decode_candidate]
+// [phase:3 decode_candidate: DPP helpers]
 // XOR / sum over each row of 16 lanes (a decode group), result in every lane: four DPP steps (VALU
 // latency each) instead of four ds_bpermute round trips through the LDS.
 #define ADSB_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
@@ -328,6 +328,7 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
 // Lane l slices frame byte l (magnitudes off+16+16l .. +15, demod.rs:97-101).  The 24-byte record
 // {offset, bytes[14], status, fixed_bit} is written to `rec` (LDS); returns (on every lane) whether the
 // frame is valid (CRC matched, or one data bit repaired: crc.rs:49-65).
+// [phase:3 slice_byte (helper; inlined twice)]
 // The PPM slice of one frame byte (demod.rs:92-131 + 180-201 in closed form): bit (7-k) = m[16 lb + 2k] > m[16 lb + 2k + 1]
 // over the magnitudes off+16+16*lb .. +15 of the tile in LDS; strict, a tie gives 0.
 template <int ST>
@@ -359,6 +360,7 @@ __device__ __forceinline__ uint32_t slice_byte(const typename MagT<ST>::type *ma
     return byte;
 }
 
+// [phase:3 decode_candidate (tiles without slots only: cold)]
 template <int ST, bool NIBBLES = false>
 __device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *mag, const uint32_t *syn, unsigned char *rec,
                                                  const bool have, const uint32_t off, const uint64_t sample0,
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         __syncthreads();
         TSTAMP(4); // barrier
 
-        // [phase:3 hand-over: survivor offsets to the frame slots]
+        // [phase:3 hand-over: slots, offsets, sliced bytes]
         // ---- phase 3: PPM slice of the gate survivors; the CRC stage is a kernel of its own --------------------
         // Every survivor gets a frame slot, its absolute offset and its 14 sliced bytes (the magnitudes are here, in
         // LDS).  CRC-24, repair, ordering inside the tile and the valid-frame count are finish_candidates' work, one

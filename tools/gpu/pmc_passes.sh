@@ -19,8 +19,8 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "demod_tiles_fused_pass" in k: k = "demod_tiles_fused_pass"
-        elif "demod_tiles" in k: k = "demod_tiles"
+        if "demod_tiles" in k: k = "demod_tiles"
+        elif "finish_candidates" in k: k = "finish_candidates"
         elif "demod_stream" in k: k = "demod_stream"
         elif "gather_tiles" in k: k = "gather_tiles"
         elif "read_only" in k: k = "read_only"

@@ -20,4 +20,4 @@ TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 f=$(find gpurun_out/prof16 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r_kernel_stats_16g.csv
 for f in r_bench r_bench_cs16 r_bench_16g r_bench_cs16_16g r_bench_64ch; do python3 -c "
 import json; d=json.load(open('gpurun_out/$f.json')); r=d['roofline']; fp=r.get('fused_pass',{})
-print('$f', r['kernel'], 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'GB/s', r['achieved'], 'frac', r['frac'], 'ceil', r['read_ceiling_gbps'], 'fused_ms', fp.get('kernel_ms'), 'fused_frac', fp.get('frac'))"; done
+print('$f', r['kernel'], 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'GB/s', r['achieved'], 'frac', r['frac'], 'ceil', r['read_ceiling_gbps'], 'finish_ms', r.get('finish_pass_ms'), 'order_ms', r.get('order_pass_ms'))"; done

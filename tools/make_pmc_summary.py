@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Builds profiles/pmc_summary.json from the PMC passes tools/gpu/round_profiles.sh left in gpurun_out/
+(r_pmc_summary_i8.json, r_pmc_summary_i16.json) and copies the round's bench lines / kernel stats into profiles/."""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
+
+def derived(d, samples, bps):
+    w = d["SQ_WAVES"]
+    return {
+        "valu_instructions_per_wave": round(d["SQ_INSTS_VALU"] / w, 1),
+        "valu_active_quad_cycles_per_wave": round(d["SQ_ACTIVE_INST_VALU"] / w, 1),
+        "valu_lane_slots_per_sample": round(d["SQ_ACTIVE_INST_VALU"] * 64 / samples, 2),
+        "wave_life_quad_cycles": round(d["SQ_WAVE_CYCLES"] / w, 1),
+        "wait_any_share_of_wave_life": round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 3),
+        "wait_inst_any_share_of_wave_life": round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 3),
+        "valu_active_over_busy_cu_cycles": round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_BUSY_CU_CYCLES"], 3),
+        "lds_bank_conflict_share_of_lds_active": round(d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1), 3),
+        "hbm_bytes_per_launch_fetch_size_x2": int(d["FETCH_SIZE"] * 1024 * 2),
+        "algorithmic_bytes_per_launch": samples * bps,
+    }
+
+
+i8 = json.load(open(os.path.join(G, "r_pmc_summary_i8.json")))
+i16 = json.load(open(os.path.join(G, "r_pmc_summary_i16.json")))
+old = json.load(open(os.path.join(P, "pmc_summary.json")))
+before = old.get("before_the_split") or {"note": "demod_tiles with the whole decode inside (round 1 .. mid round 2)",
+                                         "i8": old.get("i8", {}).get("demod_tiles", {}).get("derived"),
+                                         "i8_fused_pass_only": (old.get("i8", {}).get("demod_tiles_fused_pass") or {}).get("derived"),
+                                         "cs16": old.get("cs16", {}).get("demod_tiles", {}).get("derived"),
+                                         "round_1": old.get("round_1")}
+new = {
+    "round": "round 2",
+    "note": "rocprofv3 --pmc passes over `bench.py --steps 4 --warmup 1` (tools/gpu/pmc_passes.sh; `--sample-type i16` for CS16), "
+            "mean per launch of the named kernel on the 1 GiB workload; FETCH_SIZE is in KiB and is doubled per MI355X_MICROARCH.md "
+            "(gfx950 reports half of a wide streaming read); SQ_* cycle counters are in quad-cycles summed over waves, GRBM_GUI_ACTIVE "
+            "is summed over the 8 XCDs.  demod_tiles = the scan kernel (magnitude + gate + PPM slice of survivors), "
+            "finish_candidates = CRC-24 / repair / ordering of the survivors, gather_tiles = the ordering pass.",
+    "demod_tiles_hbm_bytes_per_launch": int(i8["demod_tiles"]["FETCH_SIZE"] * 1024 * 2),
+    "demod_tiles_i16_hbm_bytes_per_launch": int(i16["demod_tiles"]["FETCH_SIZE"] * 1024 * 2),
+    "algorithmic_bytes_per_launch": 1073741824,
+    "i8": {"demod_tiles": {"derived": derived(i8["demod_tiles"], 1 << 29, 2), "raw": i8["demod_tiles"]},
+           "finish_candidates": i8.get("finish_candidates"), "gather_tiles": i8.get("gather_tiles"),
+           "read_only_kernel": i8.get("read_only")},
+    "cs16": {"demod_tiles": {"derived": derived(i16["demod_tiles"], 1 << 28, 4), "raw": i16["demod_tiles"]},
+             "finish_candidates": i16.get("finish_candidates")},
+    "before_the_split": before,
+}
+json.dump(new, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
+for src, dst in (("r_bench.json", "bench.json"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
+                 ("r_bench_cs16_16g.json", "bench_cs16_16GiB.json"), ("r_bench_64ch.json", "bench_64_channels.json"),
+                 ("r_kernel_stats.csv", "kernel_stats.csv"), ("r_kernel_stats_16g.csv", "kernel_stats_16GiB.csv")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, f"{tag}_{dst}"))
+for k in ("i8", "cs16"):
+    print(k, json.dumps(new[k]["demod_tiles"]["derived"]))
