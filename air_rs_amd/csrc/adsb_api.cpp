@@ -429,12 +429,12 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, da, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
     // second kernel: slice + CRC of the survivors the scan kernel listed (the experimental streaming kernel decodes
     // in place and marks its tiles decoded; measurement mode stops after the scan)
-    if (!c->fused_pass_only)
-        HIPCHK(adsbk::launch_decode(c->stream, c->cfg.sample_type, c->mag_mode, da, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr));
-    if (c->own_aux) {
+    if (c->own_aux) { // (ADSB_OVERLAP_ORDERING=1: the two small kernels run beside the next launch's scan)
         HIPCHK(hipEventRecord(r.k_done, c->stream));
         HIPCHK(hipStreamWaitEvent(c->aux, r.k_done, 0));
     }
+    if (!c->fused_pass_only)
+        HIPCHK(adsbk::launch_decode(c->aux, c->cfg.sample_type, c->mag_mode, da, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr));
     HIPCHK(adsbk::launch_gather(c->aux, compact_args(c, r, i % 3u, (int)((i + 2u) % 3u), 0, c->last_tiles, false),
                                 ev ? ev[2] : nullptr, ev ? ev[3] : nullptr));
     // (same stream: in-order already; adsb_stream_wait_results records the event when somebody asks for it)

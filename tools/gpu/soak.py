@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box helper: randomized parity soak.  For `--seconds` of wall time: random buffer length, synthetic
-source parameters (frame density, noise level, error mix), sample type and i8 kernel; the HIP path's frame
+source parameters (frame density, noise level, error mix), sample type, and now and then a dense input on a
+small-capacity context (slot-pool overflow, host re-plan); the HIP path's frame
 list must equal the CPU oracle's.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,11 +15,11 @@ ap.add_argument("--seed", type=int, default=1)
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 orc = Oracle()
-ctx = {}
-for kern in ("stream", "tiles"):
-    os.environ["ADSB_KERNEL"] = kern
-    ctx[(A.ADSB_SAMPLE_I8, kern)] = A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 19)
-ctx[(A.ADSB_SAMPLE_I16, "tiles")] = A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 22, max_out=1 << 19)
+ctx = {(A.ADSB_SAMPLE_I8, "tiles"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 19),
+       (A.ADSB_SAMPLE_I16, "tiles"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 22, max_out=1 << 19),
+       # small frame capacity: dense inputs (coarse alphabets, constant stretches) overflow the slot pool and are re-planned
+       (A.ADSB_SAMPLE_I8, "small"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 20, max_out=3000),
+       (A.ADSB_SAMPLE_I16, "small"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 20, max_out=3000)}
 t0 = time.time()
 runs = fails = frames_total = 0
 t_note = t0
@@ -27,8 +28,11 @@ while time.time() - t0 < args.seconds:
         t_note = time.time()
         print(f"  ... {runs} buffers, {fails} mismatches after {t_note - t0:.0f} s", flush=True)
     st = A.ADSB_SAMPLE_I8 if rng.random() < 0.7 else A.ADSB_SAMPLE_I16
-    kern = "tiles" if st == A.ADSB_SAMPLE_I16 else ("stream" if rng.random() < 0.5 else "tiles")
+    kern = "tiles"
     n = int(rng.choice([rng.integers(240, 4000), rng.integers(4000, 200000), rng.integers(200000, 3000000)]))
+    dense = rng.random() < 0.06
+    if dense:
+        kern, n = "small", min(n, 1 << 20)
     cfg = A.synth_default(seed=int(rng.integers(1, 1 << 40)), slot_len=int(rng.choice([300, 600, 2000, 9000])))
     cfg.noise_div = int(rng.choice([3, 8, 18, 60, 200]))
     cfg.pct_flip_data = int(rng.integers(0, 30)); cfg.pct_flip_crc = int(rng.integers(0, 10)); cfg.pct_flip_two = int(rng.integers(0, 10))
@@ -36,6 +40,15 @@ while time.time() - t0 < args.seconds:
     if st == A.ADSB_SAMPLE_I16:
         cfg.amp_shift = int(rng.integers(0, 8))
     iq = A.synth_fill_host(cfg, st, int(rng.integers(0, 4)), int(rng.integers(0, 1 << 30)), n)
+    if dense:  # every offset of a constant stretch is a frame; a two-level alphabet makes many ties
+        mode = int(rng.integers(0, 3))
+        if mode == 0:
+            a, b = sorted(int(x) for x in rng.integers(0, n + 1, size=2))
+            iq[a:b] = int(rng.integers(-3, 4))
+        elif mode == 1:
+            iq = rng.choice(np.array([-1, 0, 1], dtype=iq.dtype), size=iq.shape)
+        else:
+            iq[:] = 0
     d = ctx[(st, kern)]
     got, flags = d.demod(iq)
     rc, want, found = orc.process_buffer(iq, max_out=d.max_out)
