@@ -48,14 +48,15 @@ __device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b)
     u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
     return __builtin_bit_cast(uint32_t, r);
 }
-// Three-input packed max/min.  i8 input: magnitudes are <= 181, so a packed pair is two small
-// non-negative f16 bit patterns (denormals, whose numeric order is their integer order) and gfx950's
-// v_pk_maximum3_f16 / v_pk_minimum3_f16 reduce three of them in one instruction.  i16 input:
-// magnitudes reach 46340 (not an ordered f16 pattern), so two integer v_pk_max_u16 / v_pk_min_u16.
+// Three-input packed max/min.  F16 = every value is below 0x7C00, i.e. a non-negative finite f16 BIT PATTERN
+// (denormal or normal), whose numeric order is its integer order: gfx950's v_pk_maximum3_f16 /
+// v_pk_minimum3_f16 then reduce three packed pairs in one instruction.  True for i8 input always (magnitudes
+// <= 181) and for a CS16 tile whose largest magnitude is below 31744 (checked per tile in phase 1); otherwise
+// (CS16 magnitudes reach 46340: infinities, NaNs, negative patterns) two integer v_pk_max_u16 / v_pk_min_u16.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-template <int ST> __device__ __forceinline__ uint32_t pkmax3(uint32_t a, uint32_t b, uint32_t c)
+template <bool F16> __device__ __forceinline__ uint32_t pkmax3(uint32_t a, uint32_t b, uint32_t c)
 {
-    if (ST == ADSB_SAMPLE_I8) {
+    if (F16) {
         f16x2 r = __builtin_elementwise_maximum(
             __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
             __builtin_bit_cast(f16x2, c));
@@ -63,9 +64,9 @@ template <int ST> __device__ __forceinline__ uint32_t pkmax3(uint32_t a, uint32_
     }
     return pkmax(pkmax(a, b), c);
 }
-template <int ST> __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c)
+template <bool F16> __device__ __forceinline__ uint32_t pkmin3(uint32_t a, uint32_t b, uint32_t c)
 {
-    if (ST == ADSB_SAMPLE_I8) {
+    if (F16) {
         f16x2 r = __builtin_elementwise_minimum(
             __builtin_elementwise_minimum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
             __builtin_bit_cast(f16x2, c));
@@ -488,7 +489,7 @@ struct NoHook {
 };
 
 // [phase:2 gate: set-up]
-template <int ST, int GROUP, int RUN, int NT, int HOOK_AT = -1, class HOOK = NoHook>
+template <int ST, int GROUP, int RUN, int NT, int HOOK_AT = -1, class HOOK = NoHook, bool F16OK = (ST == ADSB_SAMPLE_I8)>
 __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, uint32_t *cand, uint16_t *list,
                                            uint32_t *count, const uint32_t tid, const uint32_t n_valid,
                                            HOOK hook = HOOK())
@@ -529,9 +530,9 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
 #pragma unroll
     for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
 #pragma unroll
-    for (int j = 3; j < 13; ++j) W3[j] = pkmax3<ST>(N[j], N[j + 1], N[j + 2]);
+    for (int j = 3; j < 13; ++j) W3[j] = pkmax3<F16OK>(N[j], N[j + 1], N[j + 2]);
 #pragma unroll
-    for (int j = 1; j < 8; ++j) F[j] = pkmax3<ST>(N[j], W3[j + 2], N[j + 5]);
+    for (int j = 1; j < 8; ++j) F[j] = pkmax3<F16OK>(N[j], W3[j + 2], N[j + 5]);
 
     // [phase:2 gate: steps]
     // GROUP consecutive steps share one wave-uniform test: their 8 x GROUP min/max instructions form one
@@ -560,9 +561,9 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
             // pairs are unpacked 26 samples ahead so the (rare) DF17 check below finds its ten
             // samples already in registers
             N[o + 25] = pair_at<ST>(ra, rb, o + 25);
-            W3[o + 13] = pkmax3<ST>(N[o + 13], N[o + 14], N[o + 15]);
-            F[o + 8] = pkmax3<ST>(N[o + 8], W3[o + 10], N[o + 13]);           // lows 8,10,11,12,13
-            const uint32_t lo = pkmax3<ST>(F[o + 1], F[o + 8], W3[o + 13]);   // + 1,3,4,5,6 + 13,14,15
+            W3[o + 13] = pkmax3<F16OK>(N[o + 13], N[o + 14], N[o + 15]);
+            F[o + 8] = pkmax3<F16OK>(N[o + 8], W3[o + 10], N[o + 13]);           // lows 8,10,11,12,13
+            const uint32_t lo = pkmax3<F16OK>(F[o + 1], F[o + 8], W3[o + 13]);   // + 1,3,4,5,6 + 13,14,15
             H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
             const uint32_t hi = pkmin(H2[o], H2[o + 7]);                      // highs 0,2,7,9
 #if ADSB_ABL_NOCMP
@@ -583,8 +584,8 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
                 const int o = o0 + gi;
                 if (GROUP == 1 || __builtin_amdgcn_ballot_w64(pa[gi] | pb[gi]) != 0) {
                     // DF17 part of the gate (demod.rs:45-54)
-                    const uint32_t dh = pkmin3<ST>(pkmin3<ST>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
-                    const uint32_t dl = pkmax3<ST>(pkmax3<ST>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
+                    const uint32_t dh = pkmin3<F16OK>(pkmin3<F16OK>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
+                    const uint32_t dl = pkmax3<F16OK>(pkmax3<F16OK>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
                     const bool da = (uint16_t)dh >= (uint16_t)dl;
                     const bool db = (dh >> 16) >= (dl >> 16);
                     const uint32_t bit = 1u << (o & 31);
@@ -674,10 +675,12 @@ __device__ __forceinline__ void issue_tile_loads(const DemodArgs &p, const TileP
             raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
 }
 
-// raw IQ -> magnitudes in LDS (u8 for i8 input, u16 for i16)
+// raw IQ -> magnitudes in LDS (u8 for i8 input, u16 for i16).  Returns (wave-uniform, CS16 only) whether this wave saw
+// a magnitude that is not an ordered f16 bit pattern (>= 0x7C00 = 31744): the gate then takes its integer form.
 template <int ST, int MAGMODE>
-__device__ __forceinline__ void magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIters], typename MagT<ST>::type *mag, uint32_t tid)
+__device__ __forceinline__ bool magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIters], typename MagT<ST>::type *mag, uint32_t tid)
 {
+    uint32_t mx = 0;
     const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * P1<ST>::kSPL;
 #pragma unroll
     for (int it = 0; it < P1<ST>::kIters; ++it) {
@@ -685,10 +688,14 @@ __device__ __forceinline__ void magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIt
             const uint32_t s = (uint32_t)it * (kThreads * P1<ST>::kSPL) + tid * P1<ST>::kSPL;
             uint32_t lo, hi;
             if (ST == ADSB_SAMPLE_I8) mags8_i8<MAGMODE>(raw[it], lo, hi);
-            else mags4_i16(raw[it], lo, hi);
+            else {
+                mags4_i16(raw[it], lo, hi);
+                mx = pkmax(mx, pkmax(lo, hi)); // (samples past the channel end read as zero)
+            }
             if (s < (uint32_t)TileCfg<ST>::kMagT) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
         }
     }
+    return ST == ADSB_SAMPLE_I16 && __builtin_amdgcn_ballot_w64(((mx & 0xFFFFu) >= 0x7C00u) || ((mx >> 16) >= 0x7C00u)) != 0;
 }
 
 // [phase:end]
@@ -761,7 +768,8 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
         TSTAMP(6);                                       // ... as its own segment
 #endif
-        magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
+        const bool wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
+        if (ST == ADSB_SAMPLE_I16 && lane == 0) misc[4 + wave] = wave_big ? 1u : 0u; // (every wave writes its own word)
         TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
         TSTAMP(2); // barrier
@@ -772,7 +780,15 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
 
         // [phase:2 gate: call]
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
-        gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
+        if (ST == ADSB_SAMPLE_I16) {
+            // CS16: the 3-input f16 gate (8 instead of 11 instructions per step) whenever every magnitude of the tile
+            // is an ordered f16 pattern -- any signal below 2/3 of full scale; the integer gate otherwise
+            const bool big = (misc[4] | misc[5] | misc[6] | misc[7]) != 0; // (workgroup-uniform)
+            if (!big) gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, true>(mag, cand, list, &misc[12], tid, n_valid);
+            else gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, false>(mag, cand, list, &misc[12], tid, n_valid);
+        } else {
+            gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
+        }
 #endif
         TSTAMP(3); // phase 2
         __syncthreads();

@@ -228,3 +228,42 @@ def test_config3_16GiB_whole_buffer(gpu, oracle):
             _eq(got, want)
         del iq
     torch.cuda.empty_cache()
+
+
+# ---- CS16: the per-tile choice between the f16 3-input gate and the integer gate ---------------------------------
+def test_cs16_gate_paths_agree_with_the_oracle(gpu, oracle):
+    """A CS16 tile whose magnitudes all lie below 31744 (0x7C00: ordered f16 bit patterns) runs the 3-input f16 gate,
+    any other tile the integer gate.  Both must be the reference's ordering test: full-range random input (integer
+    gate everywhere), a realistic stream with a few full-scale samples dropped into some tiles only (both gates in
+    one launch), and gate patterns built around the 31743 / 31744 boundary."""
+    rng = np.random.default_rng(12)
+    with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=400_000, max_out=1 << 16) as d:
+        def check(iq):
+            frames, flags = d.demod(iq)
+            rc, want, n = oracle.process_buffer(iq)
+            assert rc == 0 and flags == 0
+            _eq(frames, want)
+            return len(want)
+        # 1. full range: magnitudes up to 46340
+        check(rng.integers(-32768, 32768, size=(200_000, 2)).astype(np.int16))
+        check(rng.choice(np.array([-32768, -32767, 32766, 32767, 0], dtype=np.int16), size=(100_000, 2)))
+        # 2. a stream of frames, with full-scale spikes in tiles 1, 4 and 7 only (tile = 16384 offsets)
+        cfg = A.synth_default(seed=314, slot_len=700, amp_shift=7)
+        iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I16, 0, 0, 300_000)
+        n_clean = check(iq)
+        for t in (1, 4, 7):
+            pos = rng.integers(t * 16384, (t + 1) * 16384, size=40)
+            iq[pos] = rng.choice(np.array([-32768, 32767, 23000, -23000], dtype=np.int16), size=(40, 2))
+        assert check(iq) > 0.9 * n_clean
+        # 3. the reference's gate KAT shape (demod.rs:250-278) around the boundary: highs >= lows by one, equal, reversed
+        highs, lows = [0, 2, 7, 9], [1, 3, 4, 5, 6, 8, 10, 11, 12, 13, 14, 15]
+        for hi, lo, expect in ((31744, 31743, 1), (31743, 31743, 1), (31743, 31744, 0), (31744, 31744, 1),
+                               (46340, 31744, 1), (31743, 46340, 0), (31743, 31742, 1)):
+            buf = np.zeros((241, 2), dtype=np.int16)
+            mk = lambda m: (32767, 32767) if m == 46340 else (m, 0)   # |(32767, 32767)| = 46339.9 -> 46339; only order matters
+            buf[highs] = mk(hi)
+            buf[lows] = mk(lo)
+            frames, flags = d.demod(buf)
+            rc, want, n = oracle.process_buffer(buf)
+            _eq(frames, want)
+            assert len(frames) == expect, (hi, lo, len(frames))
