@@ -981,9 +981,13 @@ __constant__ SynSorted kSynSorted = make_syn_sorted();
 // decoder used to issue them spread over the whole scan, cost 70 us here, where 16 384 of them arrive within a few
 // microseconds on 320 addresses (measured: 0.085 ms with, 0.013 ms without them).
 // All loads of a wave's four tiles are issued before the first is used: two memory round trips per wave.
-constexpr int kFinishWaves = 16; // waves per workgroup: 64 tiles = one first-level group
-constexpr int kFinishTPW = 4;    // tiles per wave
-static_assert(kFinishWaves * kFinishTPW == (1 << kGrpShift), "one workgroup per first-level group");
+#ifndef ADSB_FINISH_TPW
+#define ADSB_FINISH_TPW 4
+#endif
+constexpr int kFinishWaves = 16;             // waves per workgroup
+constexpr int kFinishTPW = ADSB_FINISH_TPW;  // tiles per wave
+constexpr int kFinishTiles = kFinishWaves * kFinishTPW; // tiles per workgroup: a first-level group (64) or a power-of-two part of one
+static_assert(kFinishTiles <= (1 << kGrpShift) && ((1 << kGrpShift) % kFinishTiles) == 0, "a workgroup stays inside one first-level group");
 
 // One chunk (<= 64 survivors, one per lane) of one tile: w = the lane's record as loaded.  Returns the number of
 // valid frames of the chunk (wave-uniform).
@@ -1045,21 +1049,22 @@ __global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs
 {
     __shared__ uint32_t crc_tab[256];
     __shared__ uint32_t syn_sorted[128];
-    __shared__ uint32_t counts[1 << kGrpShift];
+    __shared__ uint32_t counts[64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 256) crc_tab[threadIdx.x] = kCrcTab.v[threadIdx.x];
     else if (threadIdx.x < 384) syn_sorted[threadIdx.x - 256] = kSynSorted.v[threadIdx.x - 256];
-    else if (threadIdx.x < 384 + (1 << kGrpShift)) counts[threadIdx.x - 384] = 0;
+    else if (threadIdx.x < 384 + 64) counts[threadIdx.x - 384] = 0;
     __syncthreads();
 
-    const uint32_t group = (p.tile_first >> kGrpShift) + blockIdx.x;
+    const uint32_t tile0 = (p.tile_first / kFinishTiles + blockIdx.x) * kFinishTiles; // this workgroup's first tile
+    const uint32_t group = tile0 >> kGrpShift;
     const uint32_t t_end = p.tile_first + p.tile_count;
     // ---- both memory round trips of this wave's tiles up front ---------------------------------------------------
     Seg e[kFinishTPW];
     bool live[kFinishTPW];
 #pragma unroll
     for (int i = 0; i < kFinishTPW; ++i) {
-        const uint32_t tile = (group << kGrpShift) + wave * kFinishTPW + i;
+        const uint32_t tile = tile0 + wave * kFinishTPW + i;
         const bool in_range = tile >= p.tile_first && tile < t_end; // (wave-uniform)
         e[i].base = kNoBase; e[i].cand = 0; e[i].valid = 0; e[i].decoded = 1;
         if (in_range) e[i] = p.seg[tile];
@@ -1082,7 +1087,7 @@ __global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs
     }
 #pragma unroll
     for (int i = 0; i < kFinishTPW; ++i) {
-        const uint32_t tile = (group << kGrpShift) + wave * kFinishTPW + i;
+        const uint32_t tile = tile0 + wave * kFinishTPW + i;
         uint32_t n_good = e[i].valid; // (a tile the scan kernel had to decode itself keeps its count)
         if (live[i]) {
             n_good = finish_chunk(p, e[i], 0, e[i].cand < 64u ? e[i].cand : 64u, w[i], crc_tab, syn_sorted, lane);
@@ -1105,13 +1110,13 @@ __global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs
         if (lane == 0) counts[wave * kFinishTPW + i] = n_good;
     }
     __syncthreads();
-    if (wave == 0 && p.count_groups) { // the group's counter: plain store; second level: one atomic per group
+    if (wave == 0 && p.count_groups) { // the group's counters: one add per workgroup (<= 64 / kFinishTiles arrivals per address)
         uint32_t v = counts[lane];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-        if (lane == 0) {
-            p.grp1[group] = v;
-            if (v) atomicAdd(&p.grp2[(group >> kGrpShift) * kGrp2Shards + (group & (kGrp2Shards - 1))], v);
+        if (lane == 0 && v) {
+            atomicAdd(&p.grp1[group], v); // (zeroed by the ordering pass two launches ago)
+            atomicAdd(&p.grp2[(group >> kGrpShift) * kGrp2Shards + (group & (kGrp2Shards - 1))], v);
         }
     }
 }
@@ -1121,7 +1126,7 @@ hipError_t launch_decode(hipStream_t s, int sample_type, int mag_mode, const Dem
     (void)mag_mode;
     (void)sample_type;
     if (a.tile_count == 0) return hipSuccess;
-    const uint32_t g0 = a.tile_first >> kGrpShift, g1 = (a.tile_first + a.tile_count - 1) >> kGrpShift;
+    const uint32_t g0 = a.tile_first / kFinishTiles, g1 = (a.tile_first + a.tile_count - 1) / kFinishTiles;
     hipExtLaunchKernelGGL(finish_candidates, dim3(g1 - g0 + 1), dim3(kFinishWaves * 64), 0, s, e0, e1, 0, a);
     return hipGetLastError();
 }
