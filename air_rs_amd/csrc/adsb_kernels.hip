@@ -258,6 +258,32 @@ hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]
     return hipStreamSynchronize(s);
 }
 
+// ---- experiment ("magnitudes from an LDS table"): -DADSB_LUT_MAG=F ------------------------
+// F of a tile's phase-1 sweeps take floor(sqrt(n)) from a table in LDS keyed on n = I^2+Q^2 instead of v_sqrt_f32
+// (22 + 5 instead of 44 VALU instructions per 8 samples; the LDS pays a byte gather per sample).  The table covers
+// n < kLutN; a wave whose 8 x 64 samples of a sweep contain a larger n takes the arithmetic path for that sweep.
+// Needs the short tile (-DADSB_KRUN=32): every workgroup holds its own copy of the table.
+#ifndef ADSB_LUT_MAG
+#define ADSB_LUT_MAG 0
+#endif
+constexpr int kLutN = 16384;
+struct RootTable {
+    uint8_t v[kLutN];
+};
+constexpr RootTable make_root_table()
+{
+    RootTable t{};
+    uint32_t r = 0;
+    for (uint32_t n = 0; n < (uint32_t)kLutN; ++n) {
+        if ((r + 1) * (r + 1) <= n) ++r;
+        t.v[n] = (uint8_t)r;
+    }
+    return t;
+}
+#if ADSB_LUT_MAG
+__device__ const RootTable kRootTab __attribute__((aligned(16))) = make_root_table();
+#endif
+
 // ---- the fused tile kernel ------------------------------------------------------------------
 template <int ST> struct MagT;
 template <> struct MagT<ADSB_SAMPLE_I8> { typedef uint8_t type; };
@@ -271,7 +297,8 @@ template <int ST> struct Lds {
     static constexpr int kOffSyn = kOffList + kListCap * 2;    // 112 x u32
     static constexpr int kOffRes = kOffSyn + 112 * 4;          // 16 groups x 24 B record staging
     static constexpr int kOffMisc = kOffRes + 16 * 24;         // 16 x u32
-    static constexpr int kTotal = kOffMisc + 64;
+    static constexpr int kOffTab = kOffMisc + 64;              // (ADSB_LUT_MAG builds, i8 only) floor(sqrt(n)), n < kLutN
+    static constexpr int kTotal = kOffTab + ((ADSB_LUT_MAG && ST == ADSB_SAMPLE_I8) ? kLutN : 0);
 };
 
 // [phase:2 gate: unpack (helpers)]
@@ -588,9 +615,11 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
                     const uint32_t dl = pkmax3<F16OK>(pkmax3<F16OK>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
                     const bool da = (uint16_t)dh >= (uint16_t)dl;
                     const bool db = (dh >> 16) >= (dl >> 16);
+                    // (offsets at or beyond n_valid are masked out of the bitmap words after the loop, in the one
+                    // tile per channel that has any, instead of two compares here)
                     const uint32_t bit = 1u << (o & 31);
-                    if (pa[gi] & da & ((uint32_t)o < va)) atomicOr(candA + (o >> 5), bit);
-                    if (pb[gi] & db & ((uint32_t)o < vb)) atomicOr(candB + (o >> 5), bit);
+                    if (pa[gi] & da) atomicOr(candA + (o >> 5), bit);
+                    if (pb[gi] & db) atomicOr(candB + (o >> 5), bit);
                 }
             }
         }
@@ -605,6 +634,16 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
     for (int k = 0; k < WPR; ++k) {
         words[k] = candA[k];
         words[WPR + k] = candB[k];
+    }
+    if (n_valid < (uint32_t)(2 * NT * RUN)) { // (wave-uniform) the ragged last tile of a channel
+#pragma unroll
+        for (int k = 0; k < WPR; ++k) {
+            const uint32_t la = va > 32u * k ? va - 32u * k : 0u, lb = vb > 32u * k ? vb - 32u * k : 0u;
+            words[k] &= la >= 32u ? 0xFFFFFFFFu : ((1u << la) - 1u);
+            words[WPR + k] &= lb >= 32u ? 0xFFFFFFFFu : ((1u << lb) - 1u);
+            candA[k] = words[k]; // the dense path of phase 3 reads the bitmap itself
+            candB[k] = words[WPR + k];
+        }
     }
 #pragma unroll
     for (int k = 0; k < 2 * WPR; ++k) {
@@ -698,6 +737,69 @@ __device__ __forceinline__ bool magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIt
     return ST == ADSB_SAMPLE_I16 && __builtin_amdgcn_ballot_w64(((mx & 0xFFFFu) >= 0x7C00u) || ((mx >> 16) >= 0x7C00u)) != 0;
 }
 
+#if ADSB_LUT_MAG
+// i8 phase 1 with F table sweeps: sweeps [0, kIters-1-F) by arithmetic, then (the table is in LDS by now: barrier)
+// sweeps [kIters-1-F, kIters-1) through the table, the short last sweep by arithmetic.
+template <int MAGMODE>
+__device__ __forceinline__ void magnitudes_to_lds_lut(const u32x4 (&raw)[P1<ADSB_SAMPLE_I8>::kIters], uint8_t *mag,
+                                                      const uint8_t *tab, const u32x4 (&tb)[kLutN / (kThreads * 16)], uint32_t tid)
+{
+    constexpr int ST = ADSB_SAMPLE_I8;
+    constexpr int kIt = P1<ST>::kIters;
+    constexpr int F = ADSB_LUT_MAG < kIt - 1 ? ADSB_LUT_MAG : kIt - 1;
+    constexpr int kFirst = kIt - 1 - F;
+    // the table: global (L2) -> registers (issued before the tile's loads) -> LDS
+#pragma unroll
+    for (int j = 0; j < kLutN / (kThreads * 16); ++j)
+        reinterpret_cast<u32x4 *>(const_cast<uint8_t *>(tab))[j * kThreads + tid] = tb[j];
+#pragma unroll
+    for (int it = 0; it < kFirst; ++it) {
+        const uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
+        uint32_t lo, hi;
+        mags8_i8<MAGMODE>(raw[it], lo, hi);
+        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+    }
+    __syncthreads();
+    uint32_t r[F > 0 ? F : 1][8];
+    bool slow[F > 0 ? F : 1];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        int n[8];
+        dot4x8_sacc(raw[kFirst + f], 0, n);
+        uint32_t m = (uint32_t)n[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) m = m > (uint32_t)n[k] ? m : (uint32_t)n[k]; // (v_max3_u32 x 3 + v_max_u32)
+        slow[f] = __builtin_amdgcn_ballot_w64(m >= (uint32_t)kLutN) != 0;
+        if (__builtin_expect(slow[f], 0)) {
+            mags8_i8<MAGMODE>(raw[kFirst + f], r[f][0], r[f][1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[f][k] = tab[n[k]];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const uint32_t s = (uint32_t)(kFirst + f) * (kThreads * 8) + tid * 8;
+        uint32_t lo = r[f][0], hi = r[f][1];
+        if (!slow[f]) {
+            lo = r[f][0] | (r[f][1] << 8) | (r[f][2] << 16) | (r[f][3] << 24);
+            hi = r[f][4] | (r[f][5] << 8) | (r[f][6] << 16) | (r[f][7] << 24);
+        }
+        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+    }
+    { // the short last sweep (halo only)
+        constexpr int it = kIt - 1;
+        const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 8;
+        if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)TileCfg<ST>::kMagT) {
+            const uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
+            uint32_t lo, hi;
+            mags8_i8<MAGMODE>(raw[it], lo, hi);
+            if (s < (uint32_t)TileCfg<ST>::kMagT) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+        }
+    }
+}
+#endif
+
 // [phase:end]
 #ifndef ADSB_WAVES_PER_SIMD
 #define ADSB_WAVES_PER_SIMD (kRun >= 64 ? 4 : (kRun >= 48 ? 5 : 6))
@@ -750,6 +852,14 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         // [phase:1 magnitude (loads, stores)]
         // ---- phase 1: raw IQ -> magnitudes in LDS; the loads go out before anything else ----------------------
         u32x4 raw[P1<ST>::kIters];
+#if ADSB_LUT_MAG
+        u32x4 tb[kLutN / (kThreads * 16)];
+        if (ST == ADSB_SAMPLE_I8) {
+#pragma unroll
+            for (int j = 0; j < kLutN / (kThreads * 16); ++j)
+                tb[j] = reinterpret_cast<const u32x4 *>(kRootTab.v)[j * kThreads + tid];
+        }
+#endif
         issue_tile_loads<ST>(p, tp, true, tid, raw);
         TSTAMP(0); // prologue, loads issued
         if (tid < 112) syn[tid] = kSyn.v[tid];
@@ -768,7 +878,13 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
         TSTAMP(6);                                       // ... as its own segment
 #endif
+#if ADSB_LUT_MAG
+        bool wave_big = false;
+        if constexpr (ST == ADSB_SAMPLE_I8) magnitudes_to_lds_lut<MAGMODE>(raw, mag, smem + L::kOffTab, tb, tid);
+        else wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
+#else
         const bool wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
+#endif
         if (ST == ADSB_SAMPLE_I16 && lane == 0) misc[4 + wave] = wave_big ? 1u : 0u; // (every wave writes its own word)
         TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
