@@ -12,7 +12,10 @@ namespace adsbk {
 #ifndef ADSB_KRUN
 #define ADSB_KRUN 64
 #endif
-constexpr int kThreads = 256;   // 4 waves per workgroup
+#ifndef ADSB_THREADS
+#define ADSB_THREADS 256
+#endif
+constexpr int kThreads = ADSB_THREADS; // 4 waves per workgroup (a multiple of 64; the tile length scales with it)
 constexpr int kRun = ADSB_KRUN; // consecutive offsets one lane slides over, per packed half (<= 64)
 constexpr int kTile = 2 * kThreads * kRun; // offsets owned by one workgroup (32768 at kRun 64)
 constexpr int kHalo = 256;      // >= 239 extra samples so PPM never leaves the tile; 16-aligned

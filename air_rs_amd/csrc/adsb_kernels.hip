@@ -899,7 +899,10 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         if (ST == ADSB_SAMPLE_I16) {
             // CS16: the 3-input f16 gate (8 instead of 11 instructions per step) whenever every magnitude of the tile
             // is an ordered f16 pattern -- any signal below 2/3 of full scale; the integer gate otherwise
-            const bool big = (misc[4] | misc[5] | misc[6] | misc[7]) != 0; // (workgroup-uniform)
+            uint32_t any_big = 0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) any_big |= misc[4 + w];
+            const bool big = any_big != 0; // (workgroup-uniform)
             if (!big) gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, true>(mag, cand, list, &misc[12], tid, n_valid);
             else gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, false>(mag, cand, list, &misc[12], tid, n_valid);
         } else {
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         // verdict yet) into the survivor's slot: 16 survivors per workgroup round
         const uint32_t g = tid >> 4, l = tid & 15;
         auto slice_round = [&](uint32_t slot0, uint32_t ncl) {
-            for (uint32_t r = 0; r < ncl; r += 16) {
+            for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
                 if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a survivor
                 const uint32_t ci = r + g;
                 const bool have = ci < ncl; // uniform within the 16-lane group
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 } else {
                     // The slot store is full (pathological input: SURVEY F8).  The host re-plans from exact counts,
                     // so this tile's survivors are decoded HERE, from the magnitudes in LDS, only to be counted.
-                    for (uint32_t r = 0; r < ncl; r += 16) {
+                    for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
                         if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a candidate
                         const uint32_t ci = r + g;
                         const bool have = ci < ncl; // uniform within the 16-lane group
