@@ -128,16 +128,23 @@ class BucketGather:
     inside the timed region).
     """
 
-    def __init__(self, dist, cap_frames: int, bucket: int = 8, device="cpu", keep: bool = False, dst: int = 0):
+    def __init__(self, dist, cap_frames: int, bucket: int = 8, device="cpu", keep: bool = False, dst: int = 0,
+                 host_staged: bool = False):
         import torch
         self.torch = torch
         self.dist, self.rank, self.world, self.dst = dist, dist.get_rank(), dist.get_world_size(), dst
         self.bucket, self.payload, self.keep = int(bucket), payload_bytes(cap_frames), keep
         self.cuda = str(device).startswith("cuda")
+        # host_staged (rehearsals only: several ranks sharing ONE GPU, where RCCL refuses to form a communicator):
+        # the launches still write into device buckets, a flushed bucket is copied to pinned host memory on the side
+        # stream and gathered with a CPU backend (gloo).  Blocking; not for timing.
+        self.host_staged = bool(host_staged) and self.cuda
         size = self.bucket * self.payload
         self.buf = [torch.zeros(size, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = [[torch.empty(size, dtype=torch.uint8, device=device) for _ in range(self.world)]
+        rdev = "cpu" if self.host_staged else device
+        self.recv = [[torch.empty(size, dtype=torch.uint8, device=rdev) for _ in range(self.world)]
                      if self.rank == dst else None for _ in range(2)]
+        self.stage = [torch.empty(size, dtype=torch.uint8).pin_memory() for _ in range(2)] if self.host_staged else None
         self.side = torch.cuda.Stream() if self.cuda else None
         self.pending = [None, None]       # outstanding gather per half
         self.filled = [0, 0]              # launches in the gather outstanding / last completed per half
@@ -178,6 +185,12 @@ class BucketGather:
         if self.cuda:
             if wait_results is not None:
                 wait_results(self.side.cuda_stream)   # side stream waits for the last ordering pass
+            if self.host_staged:
+                with torch.cuda.stream(self.side):
+                    self.stage[bk].copy_(self.buf[bk], non_blocking=True)
+                self.side.synchronize()
+                self.pending[bk] = self.dist.gather(self.stage[bk], self.recv[bk], dst=self.dst, async_op=True)
+                return
             with torch.cuda.stream(self.side):
                 self.pending[bk] = self.dist.gather(self.buf[bk], self.recv[bk], dst=self.dst, async_op=True)
         else:

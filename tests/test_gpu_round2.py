@@ -193,6 +193,39 @@ def test_bench_gather_path_world1(gpu):
     assert d["dtype"] == "i8" and d["roofline"]["kernel_ms"] > 0
 
 
+def test_bench_three_ranks_share_one_gpu(gpu):
+    """The N-GPU path of bench.py with three REAL ranks, launched the way the driver launches it (torch.distributed.run,
+    one process per rank), all on the one GPU a box has: shard plan, stream base, result targets in device buckets, the
+    bucketed gather (11 steps: a full bucket of 8 and a partial one), rank 0's global-order and planted-frame checks.
+    RCCL refuses two ranks on one device, so the lists travel over gloo through pinned host memory
+    (ADSB_BENCH_REHEARSAL=1); a single-rank run of the same stream slices gives the expected frame count."""
+    world, n = 3, 1 << 24
+    env = dict(os.environ, ADSB_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    port = 29900 + os.getpid() % 90
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(world), "--steps", "11", "--warmup", "3", "--samples", str(n), "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    g = d["gather_check"]
+    assert d["n_gpus"] == world and "rehearsal" in d
+    assert g["globally_ordered"] and g["spot_checked_frames"] >= world and g["frames"] == d["config"]["frames_per_step"]
+    # the same three slices of the stream through one context in this process
+    own = n - A.WINDOW
+    cfg = A.synth_default()
+    want = 0
+    with A.AdsbDemod(max_samples=n, max_out=n // cfg.slot_len + 8192) as dm:
+        for rk in range(world):
+            iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, rk * own, n)
+            frames, _ = dm.demod(iq)
+            want += len(frames)
+    assert g["frames"] == want, (g["frames"], want)
+
+
 # ---- BASELINE.json configs[2] at full size: 16 GiB of i8 IQ resident on one MI355X ------------------------------
 def test_config3_16GiB_whole_buffer(gpu, oracle):
     import torch
