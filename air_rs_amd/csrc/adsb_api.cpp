@@ -220,7 +220,11 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         // instead of 9) and the step does not get shorter.
         const char *ov = getenv("ADSB_OVERLAP_ORDERING");
         if (ov && ov[0] == '1') {
-            if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
+            // (highest priority: its two small kernels should take the CU slots the scan's workgroups free, not wait
+            // for the next launch's whole grid)
+            int pr_lo = 0, pr_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+            if (hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, pr_hi) != hipSuccess) { fail(ADSB_E_NODEVICE); break; }
             c->own_aux = true;
         } else {
             c->aux = c->stream;
@@ -426,13 +430,13 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
         ev = c->ev[c->ev_count % kTimingRing];
     }
     const adsbk::DemodArgs da = demod_args(c, r, i % 3u, 0, c->last_tiles, true);
-    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, da, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
+    // (ADSB_OVERLAP_ORDERING=1: the two small kernels run beside the next launch's scan.  The event the other stream
+    // waits for rides on the scan's own dispatch packet: no barrier packet between two scans.)
+    hipEvent_t scan_done = ev ? ev[1] : (c->own_aux ? r.k_done : nullptr);
+    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, da, ev ? ev[0] : nullptr, scan_done));
     // second kernel: slice + CRC of the survivors the scan kernel listed (the experimental streaming kernel decodes
     // in place and marks its tiles decoded; measurement mode stops after the scan)
-    if (c->own_aux) { // (ADSB_OVERLAP_ORDERING=1: the two small kernels run beside the next launch's scan)
-        HIPCHK(hipEventRecord(r.k_done, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->aux, r.k_done, 0));
-    }
+    if (c->own_aux && scan_done) HIPCHK(hipStreamWaitEvent(c->aux, scan_done, 0));
     if (!c->fused_pass_only)
         HIPCHK(adsbk::launch_decode(c->aux, c->cfg.sample_type, c->mag_mode, da, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr));
     HIPCHK(adsbk::launch_gather(c->aux, compact_args(c, r, i % 3u, (int)((i + 2u) % 3u), 0, c->last_tiles, false),

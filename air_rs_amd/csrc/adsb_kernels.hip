@@ -1103,7 +1103,10 @@ __constant__ SynSorted kSynSorted = make_syn_sorted();
 #ifndef ADSB_FINISH_TPW
 #define ADSB_FINISH_TPW 4
 #endif
-constexpr int kFinishWaves = 16;             // waves per workgroup
+#ifndef ADSB_FINISH_WAVES
+#define ADSB_FINISH_WAVES 16
+#endif
+constexpr int kFinishWaves = ADSB_FINISH_WAVES; // waves per workgroup
 constexpr int kFinishTPW = ADSB_FINISH_TPW;  // tiles per wave
 constexpr int kFinishTiles = kFinishWaves * kFinishTPW; // tiles per workgroup: a first-level group (64) or a power-of-two part of one
 static_assert(kFinishTiles <= (1 << kGrpShift) && ((1 << kGrpShift) % kFinishTiles) == 0, "a workgroup stays inside one first-level group");
@@ -1170,9 +1173,11 @@ __global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs
     __shared__ uint32_t syn_sorted[128];
     __shared__ uint32_t counts[64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 256) crc_tab[threadIdx.x] = kCrcTab.v[threadIdx.x];
-    else if (threadIdx.x < 384) syn_sorted[threadIdx.x - 256] = kSynSorted.v[threadIdx.x - 256];
-    else if (threadIdx.x < 384 + 64) counts[threadIdx.x - 384] = 0;
+    for (uint32_t i = threadIdx.x; i < 256 + 128 + 64; i += kFinishWaves * 64) {
+        if (i < 256) crc_tab[i] = kCrcTab.v[i];
+        else if (i < 384) syn_sorted[i - 256] = kSynSorted.v[i - 256];
+        else counts[i - 384] = 0;
+    }
     __syncthreads();
 
     const uint32_t tile0 = (p.tile_first / kFinishTiles + blockIdx.x) * kFinishTiles; // this workgroup's first tile

@@ -185,37 +185,63 @@ def main():
             dem.fetch_counts()  # waits for the last ordering pass
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    # kernel durations are sampled on every 4th launch of the timed region (every launch for very short
-    # runs): event-carrying dispatches cost a few us each; sampling keeps the loop within 1 % of untimed
-    every = 4 if args.steps >= 16 else (2 if args.steps >= 4 else 1)
-    dem.timing_enable(0 if os.environ.get("ADSB_BENCH_NO_TIMING") == "1" else every)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t0  # host time to enqueue all steps (host-bound if ~= total)
-    drain()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    demod_ms, decode_ms, order_ms, n_timed = dem.timing_read3()
-    dem.timing_enable(False)
+    def allmax(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def measure(W, K):
+        """The contract's procedure: W untimed steps, then exactly K steps between barrier + synchronize on both
+        sides; wall time = max over ranks."""
+        for _ in range(W):
+            step()
+        drain()
+        # kernel durations are sampled on every 4th launch of the timed region (every launch for very short
+        # runs): event-carrying dispatches cost a few us each; sampling keeps the loop within 1 % of untimed
+        every = 4 if K >= 16 else (2 if K >= 4 else 1)
+        dem.timing_enable(0 if os.environ.get("ADSB_BENCH_NO_TIMING") == "1" else every)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        t_enq = time.perf_counter() - t0  # host time to enqueue all steps (host-bound if ~= total)
+        drain()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        demod_ms, decode_ms, order_ms, n_timed = dem.timing_read3()
+        dem.timing_enable(False)
+        return {"dt": allmax(dt), "t_enq": t_enq, "demod_ms": demod_ms, "decode_ms": decode_ms, "order_ms": order_ms,
+                "n_timed": n_timed}
+
+    # Two measurements by the same procedure.  `cold`: straight from an idle GPU -- the first few milliseconds of
+    # load run at boost clock, then the power controller overshoots and throttles (launches 8..40 of a burst are the
+    # slowest of all), and the clock converges on its sustained value over the next ~0.1-0.2 s
+    # (profiles/r02_scan_drift.txt, r02_steps_sweep.txt).  A 25-launch run from idle (5 ms) measures that trough.
+    # `settled`: the same W + K after `settle_s` seconds of the same steps, untimed -- what a stream that keeps
+    # arriving gets, and what `value` reports.  The cold figures are in the JSON line as `cold_start`.
+    settle_s = float(os.environ.get("ADSB_BENCH_SETTLE_S", "0.4"))
+    cold = measure(args.warmup, args.steps)
+    settle_launches = 0
+    if settle_s > 0:
+        settle_launches = int(min(4000, max(32, settle_s / (cold["dt"] / args.steps))))  # same count on every rank
+        for _ in range(settle_launches):
+            step()
+        drain()
+    m = measure(args.warmup, args.steps) if settle_s > 0 else cold
+    dt, t_enq = m["dt"], m["t_enq"]
+    demod_ms, decode_ms, order_ms, n_timed = m["demod_ms"], m["decode_ms"], m["order_ms"], m["n_timed"]
 
     n_out, total, flags = dem.fetch_counts()
 
     red_dev = "cpu" if rehearsal else "cuda"
-    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     cnt = torch.tensor([float(n_out)], dtype=torch.float64, device=red_dev)
     if dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
     frames_per_step = float(cnt.item())
 
     if rank == 0:
@@ -292,6 +318,13 @@ def main():
             "frac_of_read_ceiling": round(achieved / ceil_gbps, 4) if ceil_gbps > 0 else None}
         if gather_check is not None:
             out["gather_check"] = gather_check
+        out["settle"] = {"seconds": settle_s, "launches": settle_launches,
+                         "why": "untimed steps between the cold measurement and the reported one: the power controller needs ~0.1-0.2 s of "
+                                "load to converge (boost, overshoot, recovery); ADSB_BENCH_SETTLE_S=0 reports the cold run as value"}
+        out["cold_start"] = {"what": f"the same {args.warmup} + {args.steps} steps straight from an idle GPU",
+                             "value": round(world * n * args.steps / cold["dt"] / 1e6, 1), "unit": "Msamples/s",
+                             "ms_per_step": round(cold["dt"] / args.steps * 1e3, 4), "kernel_ms": round(cold["demod_ms"], 4),
+                             "frac": round(algo_bytes / (cold["demod_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if cold["demod_ms"] > 0 else None}
         if rehearsal:
             out["rehearsal"] = f"{world} ranks sharing one GPU, frame lists over gloo through pinned host memory: a functional run of the N-GPU path, its throughput is not a measurement"
 

@@ -2,6 +2,7 @@
 # GPU box helper: PMC passes (each its own run, no tracing flags besides kernel-trace) for bench.py
 set -o pipefail
 export TMPDIR=/tmp
+export ADSB_BENCH_SETTLE_S=0   # counters per launch do not depend on the clock state: keep the passes short
 mkdir -p gpurun_out/pmc
 run_pass() {
   name=$1; shift
