@@ -617,7 +617,8 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
                     const bool db = (dh >> 16) >= (dl >> 16);
                     // (offsets at or beyond n_valid are masked out of the bitmap words after the loop, in the one
                     // tile per channel that has any, instead of two compares here)
-                    const uint32_t bit = 1u << (o & 31);
+                    uint32_t bit = 1u << (o & 31);
+                    asm("" : "+v"(bit)); // one v_mov for both stores (hipcc rematerialises the constant per exec region)
                     if (pa[gi] & da) atomicOr(candA + (o >> 5), bit);
                     if (pb[gi] & db) atomicOr(candB + (o >> 5), bit);
                 }
@@ -711,7 +712,9 @@ __device__ __forceinline__ void issue_tile_loads(const DemodArgs &p, const TileP
 #pragma unroll
     for (int it = 0; it < P1<ST>::kIters; ++it)
         if ((uint32_t)it * (kThreads * P1<ST>::kSPL) + wave_s0 < (uint32_t)TileCfg<ST>::kMagT)
-            raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)it * (kThreads * 16) + tid * 16, 0, ADSB_LOAD_AUX);
+            // (the sweep's constant goes into the SGPR offset -- no per-load VALU address; gfx950 counts it in the
+            // descriptor's bounds check: tools/ubench/soffset_probe.hip)
+            raw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16), ADSB_LOAD_AUX);
 }
 
 // raw IQ -> magnitudes in LDS (u8 for i8 input, u16 for i16).  Returns (wave-uniform, CS16 only) whether this wave saw
