@@ -375,15 +375,31 @@ __device__ __forceinline__ uint32_t slice_byte(const typename MagT<ST>::type *ma
         uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
         uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                          __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1: bit = (a > b)
-            // b - a per 16-bit half wraps (sets bit 15) exactly when a > b; no selects (v_cndmask
-            // issues four times slower than other VALU instructions here)
-            const u16x2 xa = __builtin_bit_cast(u16x2, w[k] & 0x00FF00FFu);
-            const u16x2 xb = __builtin_bit_cast(u16x2, (w[k] >> 8) & 0x00FF00FFu);
-            const uint32_t z = __builtin_bit_cast(uint32_t, (u16x2)(xb - xa)) & 0x80008000u;
-            byte |= ((z >> (8 + 2 * k)) & 0xFFu) | (z >> (25 + 2 * k));
-        }
+        // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1, bit = (a > b), MSB first: one SDWA byte compare per
+        // pair into its own SGPR pair, then byte = byte + byte + carry-in per pair (v_addc): 16 VALU instead of 33 for
+        // the packed-subtract form, no v_cndmask (which issues four times slower here).  All eight compares come
+        // first: gfx950 wants 2 wait states between a VALU writing an SGPR and a VALU reading it, and hipcc pads
+        // nothing inside asm.
+        uint64_t m0, m1, m2, m3, m4, m5, m6, m7;
+        asm("v_cmp_gt_u32_sdwa %1, %9, %9 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+            "v_cmp_gt_u32_sdwa %2, %9, %9 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+            "v_cmp_gt_u32_sdwa %3, %10, %10 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+            "v_cmp_gt_u32_sdwa %4, %10, %10 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+            "v_cmp_gt_u32_sdwa %5, %11, %11 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+            "v_cmp_gt_u32_sdwa %6, %11, %11 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+            "v_cmp_gt_u32_sdwa %7, %12, %12 src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+            "v_cmp_gt_u32_sdwa %8, %12, %12 src0_sel:BYTE_2 src1_sel:BYTE_3\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %3\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %4\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %5\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %6\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %7\n\t"
+            "v_addc_co_u32_e64 %0, vcc, %0, %0, %8"
+            : "+v"(byte), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+            : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])
+            : "vcc");
     }
     return byte;
 }
