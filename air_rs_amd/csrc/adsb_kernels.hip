@@ -1107,20 +1107,23 @@ __constant__ SynSorted kSynSorted = make_syn_sorted();
 
 // finish_candidates: the second kernel of a launch.  The scan kernel (demod_tiles) left, per tile, `Seg{base, cand}` and,
 // in the slots base .. base+cand-1, every gate survivor's absolute offset and 14 sliced bytes (unordered when cand <=
-// kSparseCap, ascending otherwise).  One workgroup of 16 waves takes one GROUP of 64 consecutive tiles (the unit of the
-// gather pass's first-level counters), four tiles per wave, one LANE per survivor: the lane loads its 24-byte record,
+// kSparseCap, ascending otherwise).  One workgroup of 16 waves takes 32 consecutive tiles (half a GROUP of 64, the unit
+// of the gather pass's first-level counters), two tiles per wave, one LANE per survivor: the lane loads its 24-byte record,
 // runs the byte-wise CRC-24 over the 11 data bytes (1 KB table in LDS), compares with the received CRC; a non-zero
 // syndrome is looked up among the 88 data-bit syndromes (sorted, binary search) and that bit flipped (crc.rs:49-65: a
 // flip in the CRC field itself never matches); the lane's rank among the tile's survivors by offset (a readlane loop:
 // <= 64 per tile unless the tile is dense, and then they are already in order) is where the finished record {offset,
 // bytes, status, fixed_bit} goes, so that the gather pass finds every tile's slots in offset order.  The tile's
-// valid-frame count goes to its Seg; the workgroup sums its 64 tiles in LDS and writes the group's counter with a
-// plain store and ONE atomic to the second-level counter (4 arrivals per address).  Per-tile atomics, as the in-tile
+// valid-frame count goes to its Seg; the workgroup sums its tiles in LDS and adds the sum to the group's first- and
+// second-level counters with ONE atomic each (2 and 8 arrivals per address).  Per-tile atomics, as the in-tile
 // decoder used to issue them spread over the whole scan, cost 70 us here, where 16 384 of them arrive within a few
 // microseconds on 320 addresses (measured: 0.085 ms with, 0.013 ms without them).
-// All loads of a wave's four tiles are issued before the first is used: two memory round trips per wave.
+// All loads of a wave's tiles are issued before the first is used (two memory round trips per wave), and the tiles are
+// processed together in straight-line code: the kernel is a chain of dependent LDS lookups (11 for the CRC, 7 for
+// the search) and a readlane loop per tile, and interleaving two or four of them is what its time depends on
+// (14.8 us one tile after the other with 64-bit rank compares, 12.2 us interleaved, 11.5 us with two tiles per wave).
 #ifndef ADSB_FINISH_TPW
-#define ADSB_FINISH_TPW 4
+#define ADSB_FINISH_TPW 2 // (measured after the chains were interleaved: 1 024 threads x 2 tiles 11.5 us, x 4 12.2, 512 x 8 14.8)
 #endif
 #ifndef ADSB_FINISH_WAVES
 #define ADSB_FINISH_WAVES 16
@@ -1130,13 +1133,11 @@ constexpr int kFinishTPW = ADSB_FINISH_TPW;  // tiles per wave
 constexpr int kFinishTiles = kFinishWaves * kFinishTPW; // tiles per workgroup: a first-level group (64) or a power-of-two part of one
 static_assert(kFinishTiles <= (1 << kGrpShift) && ((1 << kGrpShift) % kFinishTiles) == 0, "a workgroup stays inside one first-level group");
 
-// One chunk (<= 64 survivors, one per lane) of one tile: w = the lane's record as loaded.  Returns the number of
-// valid frames of the chunk (wave-uniform).
-__device__ __forceinline__ uint32_t finish_chunk(const DemodArgs &p, const Seg &e, uint32_t chunk, uint32_t ncl,
-                                                 uint32_t (&w)[6], const uint32_t *crc_tab, const uint32_t *syn_sorted,
-                                                 uint32_t lane)
+// CRC-24 + single-bit repair of one record per lane (w = the record as loaded; straight-line code, no branches, so
+// that the chains of a wave's four tiles interleave): returns whether the frame is valid; w comes back finished
+// (repaired bit flipped, status and fixed_bit filled in).
+__device__ __forceinline__ bool finish_record(uint32_t (&w)[6], const bool have, const uint32_t *crc_tab, const uint32_t *syn_sorted)
 {
-    const bool have = lane < ncl;
     // frame byte i is record byte 8 + i: dword 2 + (i >> 2), byte (i & 3)
     uint32_t crc = 0;
 #pragma unroll
@@ -1153,33 +1154,29 @@ __device__ __forceinline__ uint32_t finish_chunk(const DemodArgs &p, const Seg &
     const uint32_t hit = syn_sorted[pos];
     const bool found = sm != 0 && (hit >> 7) == sm;
     const bool valid = have && (sm == 0 || found);
-    uint32_t status = 0xFFu, fixed = 0xFFu;
-    if (valid) {
-        status = sm == 0 ? 0u : 1u;
-        if (sm != 0) {
-            fixed = hit & 0x7Fu; // data bit 0..87, MSB first
-            const uint32_t bi = 8u + (fixed >> 3);                 // record byte of that bit
-            const uint32_t flip = (0x80u >> (fixed & 7u)) << (8u * (bi & 3u));
-            const uint32_t wi = bi >> 2;                           // 2, 3 or 4
-            w[2] ^= wi == 2 ? flip : 0u;
-            w[3] ^= wi == 3 ? flip : 0u;
-            w[4] ^= wi == 4 ? flip : 0u;
-        }
-    }
+    const bool fix = valid && sm != 0;
+    const uint32_t fixed = fix ? (hit & 0x7Fu) : 0xFFu;          // data bit 0..87, MSB first
+    const uint32_t status = valid ? (sm == 0 ? 0u : 1u) : 0xFFu;
+    const uint32_t bi = 8u + ((hit & 0x7Fu) >> 3);               // record byte of that bit
+    const uint32_t flip = fix ? ((0x80u >> (hit & 7u)) << (8u * (bi & 3u))) : 0u;
+    const uint32_t wi = bi >> 2;                                 // 2, 3 or 4
+    w[2] ^= wi == 2 ? flip : 0u;
+    w[3] ^= wi == 3 ? flip : 0u;
+    w[4] ^= wi == 4 ? flip : 0u;
     w[5] = (w[5] & 0xFFFFu) | (status << 16) | (fixed << 24);
-    // where the record goes: its rank by offset among the tile's survivors
-    uint32_t slot = lane;
-    if (e.cand <= (uint32_t)kSparseCap) { // unordered, and one chunk holds them all
-        uint32_t below = 0;
-        for (uint32_t k = 0; k < ncl; ++k) {
-            const uint32_t ok_lo = (uint32_t)__builtin_amdgcn_readlane((int)w[0], (int)k);
-            const uint32_t ok_hi = (uint32_t)__builtin_amdgcn_readlane((int)w[1], (int)k);
-            below += (ok_hi < w[1] || (ok_hi == w[1] && ok_lo < w[0])) ? 1u : 0u;
-        }
-        slot = below;
-    }
+    return valid;
+}
+
+// A later chunk (<= 64 survivors, one per lane) of a dense tile (more than 64 survivors: pathological input; the scan
+// kernel left them in offset order).  Returns the number of valid frames of the chunk (wave-uniform).
+__device__ __forceinline__ uint32_t finish_chunk(const DemodArgs &p, const Seg &e, uint32_t chunk, uint32_t ncl,
+                                                 uint32_t (&w)[6], const uint32_t *crc_tab, const uint32_t *syn_sorted,
+                                                 uint32_t lane)
+{
+    const bool have = lane < ncl;
+    const bool valid = finish_record(w, have, crc_tab, syn_sorted);
     if (have) {
-        uint2 *dst = reinterpret_cast<uint2 *>(p.slots + (size_t)e.base + chunk + slot);
+        uint2 *dst = reinterpret_cast<uint2 *>(p.slots + (size_t)e.base + chunk + lane);
 #pragma unroll
         for (int k = 0; k < 3; ++k) dst[k] = make_uint2(w[2 * k], w[2 * k + 1]);
     }
@@ -1228,16 +1225,50 @@ __global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs
             }
         }
     }
+    // ---- first chunk of all of this wave's tiles together: no branch on a tile's state, so the four CRC / search
+    // chains (dependent LDS lookups) and the four rank loops interleave instead of running one after the other ------
+    uint32_t ncl[kFinishTPW];
+    bool valid[kFinishTPW];
+#pragma unroll
+    for (int i = 0; i < kFinishTPW; ++i) {
+        ncl[i] = live[i] ? (e[i].cand < 64u ? e[i].cand : 64u) : 0u;
+        valid[i] = finish_record(w[i], lane < ncl[i], crc_tab, syn_sorted);
+    }
+    // where a record goes: its rank by offset among the tile's survivors (<= kSparseCap = 64 of them arrive unordered;
+    // more than that arrive in order).  A tile's offsets lie within 2^15 of each other: the low words relative to
+    // lane 0's order them (wrap-safe); one v_readlane + compare + add per survivor and tile.
+    uint32_t ref[kFinishTPW], below[kFinishTPW], nrank[kFinishTPW], kmax = 0;
+    int32_t mine[kFinishTPW];
+#pragma unroll
+    for (int i = 0; i < kFinishTPW; ++i) {
+        ref[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i][0]);
+        mine[i] = (int32_t)(w[i][0] - ref[i]);
+        below[i] = 0;
+        nrank[i] = (live[i] && e[i].cand <= (uint32_t)kSparseCap) ? ncl[i] : 0u;
+        kmax = nrank[i] > kmax ? nrank[i] : kmax;
+    }
+    for (uint32_t k = 0; k < kmax; ++k) {
+#pragma unroll
+        for (int i = 0; i < kFinishTPW; ++i) {
+            const int32_t other = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)w[i][0], (int)k) - ref[i]);
+            below[i] += (k < nrank[i] && other < mine[i]) ? 1u : 0u;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < kFinishTPW; ++i) {
         const uint32_t tile = tile0 + wave * kFinishTPW + i;
-        uint32_t n_good = e[i].valid; // (a tile the scan kernel had to decode itself keeps its count)
+        const uint32_t slot = nrank[i] ? below[i] : lane;
+        if (lane < ncl[i]) {
+            uint2 *dst = reinterpret_cast<uint2 *>(p.slots + (size_t)e[i].base + slot);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dst[k] = make_uint2(w[i][2 * k], w[i][2 * k + 1]);
+        }
+        uint32_t n_good = live[i] ? (uint32_t)__builtin_popcountll(__ballot(valid[i])) : e[i].valid; // (a tile the scan kernel had to decode itself keeps its count)
         if (live[i]) {
-            n_good = finish_chunk(p, e[i], 0, e[i].cand < 64u ? e[i].cand : 64u, w[i], crc_tab, syn_sorted, lane);
             for (uint32_t chunk = 64; chunk < e[i].cand; chunk += 64) { // dense tile (pathological input): in order already
-                const uint32_t ncl = (e[i].cand - chunk) < 64u ? (e[i].cand - chunk) : 64u;
+                const uint32_t nc = (e[i].cand - chunk) < 64u ? (e[i].cand - chunk) : 64u;
                 uint32_t x[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
-                if (lane < ncl) {
+                if (lane < nc) {
                     const uint2 *src = reinterpret_cast<const uint2 *>(p.slots + (size_t)e[i].base + chunk + lane);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -1246,7 +1277,7 @@ __global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs
                         x[2 * k + 1] = v.y;
                     }
                 }
-                n_good += finish_chunk(p, e[i], chunk, ncl, x, crc_tab, syn_sorted, lane);
+                n_good += finish_chunk(p, e[i], chunk, nc, x, crc_tab, syn_sorted, lane);
             }
             if (lane == 0) p.seg[tile].valid = n_good;
         }
