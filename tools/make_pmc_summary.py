@@ -51,6 +51,20 @@ new = {
     "cs16": {"demod_tiles": {"derived": derived(i16["demod_tiles"], 1 << 28, 4), "raw": i16["demod_tiles"]},
              "finish_candidates": i16.get("finish_candidates")},
     "before_the_split": before,
+    # the scan kernel's PMC rows as it was trimmed after the split (each measured by the same passes, one MI355X box each)
+    "demod_tiles_i8_history": old.get("demod_tiles_i8_history") or [
+        {"what": "whole decode inside demod_tiles (round 1 .. mid round 2)", "valu_instructions_per_wave": 1539, "valu_slots_per_wave": 1674},
+        {"what": "the split: CRC / repair / ordering in finish_candidates", "valu_instructions_per_wave": 1432, "valu_slots_per_wave": 1567.1},
+        {"what": "n_valid masking out of the DF17 block", "valu_instructions_per_wave": 1411.7, "valu_slots_per_wave": 1546.8},
+        {"what": "tile loads: sweep constant in the SGPR offset; one register for the DF17 bit constant", "valu_instructions_per_wave": 1386.3, "valu_slots_per_wave": 1521.4},
+        {"what": "slicer: SDWA byte compare + add-with-carry per bit", "valu_instructions_per_wave": 1367.4, "valu_slots_per_wave": 1502.5},
+    ],
+    "demod_tiles_cs16_history": old.get("demod_tiles_cs16_history") or [
+        {"what": "whole decode inside demod_tiles", "valu_instructions_per_wave": 1155, "valu_slots_per_wave": 1223},
+        {"what": "the split", "valu_instructions_per_wave": 1085, "valu_slots_per_wave": 1155},
+        {"what": "per-tile f16 gate", "valu_instructions_per_wave": 999.8, "valu_slots_per_wave": 1069.5},
+        {"what": "n_valid masking, SGPR load offsets, DF17 constant", "valu_instructions_per_wave": 972.9, "valu_slots_per_wave": 1042.6},
+    ],
 }
 json.dump(new, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 for src, dst in (("r_bench.json", "bench.json"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
