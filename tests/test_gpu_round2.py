@@ -189,6 +189,7 @@ def test_bench_gather_path_world1(gpu):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     g = d["gather_check"]
+    assert g["ok"], g
     assert g["globally_ordered"] and g["spot_checked_frames"] >= 1 and g["frames"] == d["config"]["frames_per_step"]
     assert d["dtype"] == "i8" and d["roofline"]["kernel_ms"] > 0
     # the line carries both regimes: the reported (settled) run and the same W + K steps from an idle GPU
@@ -214,6 +215,7 @@ def test_bench_three_ranks_share_one_gpu(gpu):
     line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     g = d["gather_check"]
+    assert g["ok"], g
     assert d["n_gpus"] == world and "rehearsal" in d
     assert g["globally_ordered"] and g["spot_checked_frames"] >= world and g["frames"] == d["config"]["frames_per_step"]
     # the same three slices of the stream through one context in this process
