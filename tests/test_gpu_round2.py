@@ -267,6 +267,42 @@ def test_config3_16GiB_whole_buffer(gpu, oracle):
     torch.cuda.empty_cache()
 
 
+def test_16GiB_cs16_whole_buffer(gpu, oracle):
+    """The 16 GiB size in the reference's own sample format (Complex<i16>: 4 294 967 296 samples): strictly ascending
+    offsets, the planted-frame band, sampled windows equal to the oracle incl. one across byte 2^33."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20 * (1 << 30):
+        pytest.skip(f"needs 20 GiB of free HBM, {free / 2**30:.1f} GiB available")
+    n = 1 << 32                      # samples: 16 GiB at 4 bytes each
+    cfg = A.synth_default(seed=77)
+    cfg.amp_shift = 6
+    slots = n // cfg.slot_len
+    cap = slots + 8192
+    with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=n, max_out=cap, host_staging=False,
+                     stream=torch.cuda.current_stream().cuda_stream) as d:
+        iq = torch.empty(2 * n, dtype=torch.int16, device="cuda")
+        d.synth_fill_device(cfg, 0, 0, n, iq.data_ptr())
+        d.demod_device_async(iq.data_ptr(), n)
+        frames, counts, total, flags = d.fetch()
+        assert flags == 0 and total == len(frames)
+        off = frames["offset"].astype(np.int64)
+        assert (np.diff(off) > 0).all() and off[0] >= 0 and off[-1] < n - 240
+        assert 0.935 * slots < len(frames) < 0.955 * slots, (len(frames), slots)
+        assert 0.040 * slots < int((frames["status"] == 1).sum()) < 0.060 * slots
+        L = 1 << 20
+        for a in (0, (1 << 31) - L // 2, 3 * (1 << 30) + 54_321, n - L):  # (sample 2^31 = byte 2^33)
+            sub = iq[2 * a: 2 * (a + L)].cpu().numpy().reshape(L, 2)
+            rc, want, cnt = oracle.process_buffer(sub)
+            assert rc == 0 and cnt > 400
+            lo, hi = np.searchsorted(off, a), np.searchsorted(off, a + L - 240)
+            got = frames[lo:hi].copy()
+            got["offset"] -= np.uint64(a)
+            _eq(got, want)
+        del iq
+    torch.cuda.empty_cache()
+
+
 # ---- CS16: the per-tile choice between the f16 3-input gate and the integer gate ---------------------------------
 def test_cs16_gate_paths_agree_with_the_oracle(gpu, oracle):
     """A CS16 tile whose magnitudes all lie below 31744 (0x7C00: ordered f16 bit patterns) runs the 3-input f16 gate,
