@@ -303,6 +303,35 @@ def test_16GiB_cs16_whole_buffer(gpu, oracle):
     torch.cuda.empty_cache()
 
 
+# ---- the opt-in mode that runs finish + gather on their own stream beside the next launch's scan ---------------------
+def test_overlapped_small_kernels_mode_matches_oracle(gpu, oracle, monkeypatch):
+    """ADSB_OVERLAP_ORDERING=1 (read at adsb_create): finish_candidates and gather_tiles of launch k run on a second,
+    high-priority stream behind the scan's own completion event while the scan of launch k+1 already runs.  Three
+    device-resident buffers are launched back to back, twice, with no host synchronisation in between; every launch's
+    list must be the oracle's (result sets alternate: a missing dependency shows as a mixed or stale list)."""
+    import torch
+    monkeypatch.setenv("ADSB_OVERLAP_ORDERING", "1")
+    n = 1 << 21
+    with A.AdsbDemod(max_samples=n, max_out=1 << 16, host_staging=False,
+                     stream=torch.cuda.current_stream().cuda_stream) as d:
+        bufs, wants = [], []
+        for k in range(3):
+            cfg = A.synth_default(seed=900 + k, slot_len=700)
+            host = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, n)
+            rc, want, cnt = oracle.process_buffer(host)
+            assert rc == 0 and cnt > 1000
+            bufs.append(torch.from_numpy(np.ascontiguousarray(host)).cuda())
+            wants.append(want)
+        torch.cuda.synchronize()
+        for rnd in range(2):
+            for k in (0, 1, 2, 1, 0, 2):
+                d.demod_device_async(bufs[k].data_ptr(), n)
+                if k == 2 or rnd == 1:   # (some launches are never fetched: their results are simply overwritten)
+                    frames, counts, total, flags = d.fetch()
+                    assert flags == 0
+                    _eq(frames, wants[k])
+
+
 # ---- CS16: the per-tile choice between the f16 3-input gate and the integer gate ---------------------------------
 def test_cs16_gate_paths_agree_with_the_oracle(gpu, oracle):
     """A CS16 tile whose magnitudes all lie below 31744 (0x7C00: ordered f16 bit patterns) runs the 3-input f16 gate,
