@@ -130,10 +130,9 @@ PROTOTYPES = {
     "adsb_debug_magnitudes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "adsb_debug_mag_mode": (C.c_int, [C.c_void_p]),
     "adsb_debug_fused_pass_only": (C.c_int, [C.c_void_p, C.c_int]),
-    "adsb_debug_kernel": (C.c_int, [C.c_void_p]),
-    "adsb_debug_lut": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "adsb_debug_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "adsb_debug_stamps_waves": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adsb_debug_nsq_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adsb_debug_scan": (C.c_int, [C.c_void_p]),
+    "adsb_debug_pool_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "adsb_debug_tile_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "adsb_synth_default": (None, [_P(AdsbSynthCfg)]),
     "adsb_synth_fill_host": (C.c_int, [_P(AdsbSynthCfg), C.c_int, C.c_uint32, C.c_uint64, C.c_size_t,

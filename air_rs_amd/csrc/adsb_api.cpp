@@ -77,10 +77,10 @@ struct adsb_ctx {
     uint32_t *grp = nullptr;        // three sets x (grp1[n_grp1] | grp2[n_grp2]) valid-frame counters
     uint32_t n_grp1 = 0, n_grp2 = 0;
     uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
-    uint8_t *lut = nullptr;         // i8 streaming kernel: 64 KB floor(sqrt(I^2+Q^2)) table (swizzled index)
-    unsigned long long *stamps = nullptr; // cycle counters of diagnostic builds (16 words; 64 bytes per tile with -DADSB_TILE_STAMPS=1)
+    unsigned long long *stamps = nullptr; // cycle counters of diagnostic builds (64 bytes per tile with -DADSB_TILE_STAMPS=1)
     size_t stamps_bytes = 0;
-    uint32_t stream_grid = 0;       // persistent workgroups of the streaming kernel (= CUs); 0: tile kernel
+    int scan = adsbk::kScanNsq;     // which i8 scan kernel (ADSB_SCAN=root selects the A/B kernel at adsb_create)
+    bool pool_off = false;          // adsb_debug_pool_limit: the shared slot pool hands out nothing (test knob)
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
 
@@ -107,10 +107,10 @@ struct adsb_ctx {
         if (e_ != hipSuccess) return (int)e_;      \
     } while (0)
 
-static uint32_t tiles_for(uint64_t n_samples, int sample_type, bool stream)
+static uint32_t tiles_for(uint64_t n_samples, int sample_type)
 {
     if (n_samples <= (uint64_t)kWindow) return 0;
-    const uint64_t n_off = n_samples - kWindow, tile = (uint64_t)adsbk::tile_offsets(sample_type, stream);
+    const uint64_t n_off = n_samples - kWindow, tile = (uint64_t)adsbk::tile_offsets(sample_type);
     return (uint32_t)((n_off + tile - 1) / tile);
 }
 
@@ -156,7 +156,6 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     (void)hipFree(c->trk_aircraft);
     (void)hipFree(c->trk_n_aircraft);
     (void)hipFree(c->scratch);
-    (void)hipFree(c->lut);
     (void)hipFree(c->stamps);
     (void)hipFree(c->grp);
     if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
@@ -183,14 +182,14 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     if (!c) return ADSB_E_NOMEM;
     c->cfg = *cfg;
     c->bps = cfg->sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
-    // The product has ONE i8 kernel, demod_tiles (also used for i16).  Experimental builds (tools/build_variant.sh
-    // stream -DADSB_WITH_STREAM_KERNEL=1 -Itools/experimental) also carry the streaming kernel of DESIGN.md
-    // section 4.3, selected with ADSB_KERNEL=stream at adsb_create; asking for it in a build without it is an error.
-    const char *kern = getenv("ADSB_KERNEL");
-    const bool ask_stream = kern && strcmp(kern, "stream") == 0;
-    if (ask_stream && !adsbk::stream_kernel_built()) { delete c; return ADSB_E_ARG; }
-    const bool want_stream = cfg->sample_type == ADSB_SAMPLE_I8 && ask_stream;
-    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type, want_stream) * cfg->max_channels;
+    // i8 has two scan kernels: the product's (the gate on n = I^2+Q^2, no root per sample) and the round-1/2 one
+    // (floor(sqrt) per sample), kept for A/B measurements: ADSB_SCAN=root in the environment at adsb_create.
+    if (const char *sc = getenv("ADSB_SCAN")) {
+        if (strcmp(sc, "root") == 0) c->scan = adsbk::kScanRoot;
+        else if (strcmp(sc, "nsq") == 0 || sc[0] == 0) c->scan = adsbk::kScanNsq;
+        else { delete c; return ADSB_E_ARG; }
+    }
+    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type) * cfg->max_channels;
     if (tiles == 0) tiles = 1;
     if (tiles * adsbk::kQuota + cfg->max_out + kTile > 0xFFFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
     c->n_tiles_max = (uint32_t)tiles;
@@ -258,21 +257,9 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         else if (probe[1] == want) c->mag_mode = 1;
         else c->mag_mode = 2;
         if (const char *force = getenv("ADSB_FORCE_MAG_MODE")) c->mag_mode = atoi(force) % 3;
-        // cycle counters of diagnostic builds (-DADSB_TILE_STAMPS=1, -DADSB_STAMPS=1); zeros otherwise
+        // cycle counters of diagnostic builds (-DADSB_TILE_STAMPS=1); zeros otherwise
         c->stamps_bytes = adsbk::tile_stamps_built() ? (size_t)c->n_tiles_max * 64 + 512 : 512;
         if (hipMalloc((void **)&c->stamps, c->stamps_bytes) != hipSuccess || hipMemsetAsync(c->stamps, 0, c->stamps_bytes, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
-        if (want_stream) {
-            int n_cu = 0;
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || n_cu <= 0) {
-                fail(ADSB_E_NODEVICE);
-                break;
-            }
-            if (hipMalloc((void **)&c->lut, 65536) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
-            e = adsbk::launch_build_lut(c->stream, c->lut);
-            if (e != hipSuccess) { fail((int)e); break; }
-            c->stream_grid = (uint32_t)n_cu;
-            if (const char *g = getenv("ADSB_STREAM_GRID")) { int v = atoi(g); if (v > 0) c->stream_grid = (uint32_t)v; }
-        }
     } while (0);
     if (rc != ADSB_OK) { adsb_destroy(c); return rc; }
     *out_ctx = c;
@@ -288,15 +275,11 @@ extern "C" int adsb_debug_fused_pass_only(adsb_ctx *c, int on)
     return ADSB_OK;
 }
 extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
-extern "C" int adsb_debug_kernel(adsb_ctx *c) { return c ? (c->stream_grid ? 1 : 0) : ADSB_E_ARG; }
-
-extern "C" int adsb_debug_stamps(adsb_ctx *c, uint64_t out16[16])
+extern "C" int adsb_debug_scan(adsb_ctx *c) { return c ? (c->cfg.sample_type == ADSB_SAMPLE_I8 ? c->scan : adsbk::kScanRoot) : ADSB_E_ARG; }
+extern "C" int adsb_debug_pool_limit(adsb_ctx *c, int on)
 {
-    if (!c || !out16) return ADSB_E_ARG; // (slots 16..31, per-wave busy cycles, via adsb_debug_stamps_waves)
-    if (!c->stamps) return ADSB_E_STATE;
-    HIPCHK(hipSetDevice(c->cfg.device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out16, c->stamps, 128, hipMemcpyDeviceToHost));
+    if (!c) return ADSB_E_ARG;
+    c->pool_off = on != 0;
     return ADSB_OK;
 }
 
@@ -309,26 +292,6 @@ extern "C" int adsb_debug_tile_stamps(adsb_ctx *c, uint32_t *out, size_t max_til
     const size_t n = std::min<size_t>(max_tiles, c->last_tiles);
     if (n) HIPCHK(hipMemcpy(out, c->stamps, n * 64, hipMemcpyDeviceToHost));
     *n_tiles = n;
-    return ADSB_OK;
-}
-
-extern "C" int adsb_debug_stamps_waves(adsb_ctx *c, uint64_t out16[16])
-{
-    if (!c || !out16) return ADSB_E_ARG;
-    if (!c->stamps) return ADSB_E_STATE;
-    HIPCHK(hipSetDevice(c->cfg.device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out16, c->stamps + 16, 128, hipMemcpyDeviceToHost));
-    return ADSB_OK;
-}
-
-extern "C" int adsb_debug_lut(adsb_ctx *c, uint8_t *table_host65536)
-{
-    if (!c || !table_host65536) return ADSB_E_ARG;
-    if (!c->lut) return ADSB_E_STATE;
-    HIPCHK(hipSetDevice(c->cfg.device));
-    HIPCHK(hipMemcpyAsync(table_host65536, c->lut, 65536, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     return ADSB_OK;
 }
 
@@ -356,8 +319,7 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.hdr_pub = (count_groups && c->ext_blob) ? static_cast<uint64_t *>(c->ext_blob) : nullptr;
     a.grp1 = grp1_of(c, grp_set);
     a.grp2 = grp2_of(c, grp_set);
-    a.lut = c->lut;
-    a.stream_grid = c->stream_grid;
+    a.pool_off = c->pool_off ? 1u : 0u;
     a.stamps = c->stamps;
     return a;
 }
@@ -406,7 +368,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_channels = n_channels;
     c->last_samples = n_samples;
     c->last_stride = channel_stride;
-    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type, c->stream_grid != 0);
+    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type);
     c->last_tiles = c->last_tpc * n_channels;
     c->last_base = c->stream_base;
     c->launched = true;
@@ -433,7 +395,13 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     // (ADSB_OVERLAP_ORDERING=1: the two small kernels run beside the next launch's scan.  The event the other stream
     // waits for rides on the scan's own dispatch packet: no barrier packet between two scans.)
     hipEvent_t scan_done = ev ? ev[1] : (c->own_aux ? r.k_done : nullptr);
-    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, da, ev ? ev[0] : nullptr, scan_done));
+    HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, c->scan, da, ev ? ev[0] : nullptr, scan_done));
+    if (c->last_tiles == 0) {
+        // exactly 240 samples: zero offsets (adsb.rs:98 iterates 0..0).  No scan kernel runs, so nobody clears this
+        // result set's flag words (block 0 of the scan does): the ordering pass below only ORs bits in.
+        HIPCHK(hipMemsetAsync(&r.hdr->flags, 0, sizeof(uint32_t), c->stream));
+        if (c->ext_blob) HIPCHK(hipMemsetAsync(static_cast<char *>(c->ext_blob) + 16, 0, sizeof(uint64_t), c->stream));
+    }
     // second kernel: slice + CRC of the survivors the scan kernel listed (the experimental streaming kernel decodes
     // in place and marks its tiles decoded; measurement mode stops after the scan)
     if (c->own_aux && scan_done) HIPCHK(hipStreamWaitEvent(c->aux, scan_done, 0));
@@ -500,7 +468,7 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
         if (t1 == t0) { rc = ADSB_E_STATE; break; } // a single tile never exceeds cap_slots (>= kTile)
         hipError_t e;
         if ((e = hipMemsetAsync(&r.hdr->alloc, 0, sizeof(unsigned long long), c->stream)) != hipSuccess ||
-            (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode,
+            (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, c->scan,
                                      demod_args(c, r, grp_set, t0, t1 - t0, false))) != hipSuccess ||
             (e = adsbk::launch_decode(c->stream, c->cfg.sample_type, c->mag_mode,
                                       demod_args(c, r, grp_set, t0, t1 - t0, false))) != hipSuccess ||
@@ -813,6 +781,28 @@ extern "C" int adsb_debug_magnitudes(adsb_ctx *c, const void *iq_host, size_t n,
     return rc;
 }
 
+extern "C" int adsb_debug_nsq_values(adsb_ctx *c, const void *iq_host, size_t n, uint16_t *vals_host)
+{
+    if (!c || !iq_host || !vals_host) return ADSB_E_ARG;
+    if (c->cfg.sample_type != ADSB_SAMPLE_I8) return ADSB_E_STATE;
+    if (n == 0) return ADSB_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    void *d_in = nullptr;
+    uint16_t *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_in, n * 2 + 16));
+    hipError_t e = hipMalloc((void **)&d_out, n * sizeof(uint16_t));
+    if (e != hipSuccess) { (void)hipFree(d_in); return (int)e; }
+    do {
+        if ((e = hipMemcpyAsync(d_in, iq_host, n * 2, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+        if ((e = adsbk::launch_nsq_values(c->stream, d_in, n, d_out)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(vals_host, d_out, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(c->stream);
+    } while (0);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return e == hipSuccess ? ADSB_OK : (int)e;
+}
+
 // ---- synthetic source ------------------------------------------------------------------------------
 extern "C" void adsb_synth_default(adsb_synth_cfg *s)
 {
@@ -954,6 +944,8 @@ extern "C" int adsb_feed_open(adsb_ctx *c, const adsb_feed_cfg *cfg, adsb_feed *
     // one launch covers the buffer, in carry mode with the 240 carried samples in front of it
     if (cfg->max_chunk + (cfg->carry ? (size_t)kWindow : 0) > c->cfg.max_samples) return ADSB_E_CAPACITY;
     if (c->cfg.max_channels < 1) return ADSB_E_ARG;
+    // two launches are in flight: they must not share one caller-owned result blob
+    if (c->ext_blob) return ADSB_E_STATE;
     HIPCHK(hipSetDevice(c->cfg.device));
     adsb_feed *f = new (std::nothrow) adsb_feed();
     if (!f) return ADSB_E_NOMEM;

@@ -10,19 +10,19 @@ namespace adsbk {
 
 // ---- tiling constants (see DESIGN.md "Data layout") ---------------------------------------
 #ifndef ADSB_KRUN
-#define ADSB_KRUN 64
+#define ADSB_KRUN 32
 #endif
 #ifndef ADSB_THREADS
 #define ADSB_THREADS 256
 #endif
 constexpr int kThreads = ADSB_THREADS; // 4 waves per workgroup (a multiple of 64; the tile length scales with it)
 constexpr int kRun = ADSB_KRUN; // consecutive offsets one lane slides over, per packed half (<= 64)
-constexpr int kTile = 2 * kThreads * kRun; // offsets owned by one workgroup (32768 at kRun 64)
+constexpr int kTile = 2 * kThreads * kRun; // offsets owned by one workgroup (16384 at kRun 32)
 constexpr int kHalo = 256;      // >= 239 extra samples so PPM never leaves the tile; 16-aligned
 constexpr int kMag = kTile + kHalo;
-// CS16 input keeps u16 magnitudes in LDS: with the i8 tile (32768 offsets, 66 KB) only two workgroups fit a
-// CU -- two waves per SIMD, far too few to hide the gate's latencies -- so i16 tiles are half as long
-// (runs of 32 offsets, 33 KB, four workgroups per CU).
+// Both sample types keep 16-bit values per sample in LDS (i8: n = I^2+Q^2 + a bias, or its root in the A/B kernel;
+// CS16: u16 magnitudes): runs of 32 offsets = 16384-offset tiles, 33-36 KB, four workgroups per CU.  (Runs of 64
+// with 16-bit values take 66 KB: two workgroups per CU, two waves per SIMD -- far too few to hide the gate's latencies.)
 #ifndef ADSB_KRUN_I16
 #define ADSB_KRUN_I16 32
 #endif
@@ -32,12 +32,15 @@ template <int ST> struct TileCfg {
     static constexpr int kTileT = 2 * kThreads * kRunT;
     static constexpr int kMagT = kTileT + kHalo;
 };
-// the streaming i8 kernel has its own tile length (three magnitude buffers + the table must fit the LDS)
-constexpr int kStreamTile = 2 * (64 * 7) * 32; // = kSTile in adsb_stream_kernel.h
-constexpr int tile_offsets(int sample_type, bool stream = false)
+constexpr int tile_offsets(int sample_type)
 {
-    return sample_type == ADSB_SAMPLE_I8 ? (stream ? kStreamTile : kTile) : 2 * kThreads * kRunI16;
+    return sample_type == ADSB_SAMPLE_I8 ? kTile : 2 * kThreads * kRunI16;
 }
+constexpr int kTileMax = kTile > 2 * kThreads * kRunI16 ? kTile : 2 * kThreads * kRunI16;
+// Which i8 scan kernel a context launches (adsb_create reads ADSB_SCAN from the environment; default nsq):
+//   kScanNsq : the gate runs on n = I^2+Q^2 (no root per sample; exact: DESIGN.md section 4.1)
+//   kScanRoot: the round-1/2 kernel, floor(sqrt(n)) per sample (v_sqrt_f32), kept for A/B measurements
+constexpr int kScanNsq = 0, kScanRoot = 1;
 constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
 constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path
 constexpr int kWindow = 240;    // 16 + 112*2  (reference src/adsb.rs:98)
@@ -89,11 +92,8 @@ struct DemodArgs {
     Header *hdr;
     uint64_t *hdr_pub;         // optional caller-owned header copy (adsb_set_result_target): its flags word is cleared here
     uint32_t *grp1, *grp2;     // this launch's parity
-    // streaming kernel (i8 only): the 64 KB floor(sqrt(I^2+Q^2)) table and the persistent grid size
-    // (number of CUs); stream_grid == 0 selects the one-workgroup-per-tile kernel
-    const uint8_t *lut;
-    uint32_t stream_grid;
-    unsigned long long *stamps; // diagnostic builds (-DADSB_STAMPS=1) only: 16 cycle counters of workgroup 0
+    uint32_t pool_off;         // test knob (adsb_debug_pool_limit): 1 = the shared slot pool hands out nothing
+    unsigned long long *stamps; // diagnostic builds (-DADSB_TILE_STAMPS=1) only: 64 bytes of cycle counters per tile
 };
 
 struct CompactArgs {
@@ -121,18 +121,16 @@ struct CompactArgs {
 hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]);
 
 // e0/e1: optional events recorded at the start / end of the dispatch itself (nullptr: none)
-hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
+// scan: kScanNsq / kScanRoot (i8 only; CS16 has one kernel)
+hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, const DemodArgs &a,
                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-// second kernel of a launch: PPM slice + CRC-24 + repair of the survivors the scan kernel listed (same DemodArgs)
+// second kernel of a launch (finish_candidates): CRC-24 + single-bit repair + ordering inside a tile of the survivors
+// the scan kernel sliced into their slots (same DemodArgs)
 hipError_t launch_decode(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
                          hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nullptr,
                          hipEvent_t e1 = nullptr);
 
-// 64 KB magnitude table of the experimental streaming kernel (built once per context); that kernel is only
-// present in -DADSB_WITH_STREAM_KERNEL=1 builds (tools/experimental/)
-hipError_t launch_build_lut(hipStream_t s, uint8_t *lut_dev);
-bool stream_kernel_built();
 bool tile_stamps_built(); // -DADSB_TILE_STAMPS=1 diagnostic build: DemodArgs::stamps holds 64 bytes per tile
 
 // field decode of an ordered frame list (count read from hdr->n_out on the device)
@@ -159,6 +157,8 @@ hipError_t launch_track(hipStream_t s, const TrackArgs &a);
 // test / measurement kernels
 hipError_t launch_magnitudes(hipStream_t s, int sample_type, int mag_mode, const void *iq,
                              size_t n, uint16_t *out);
+// i8: the biased squared magnitudes I^2+Q^2+72 as the nsq scan kernel's phase 1 packs them (test hook)
+hipError_t launch_nsq_values(hipStream_t s, const void *iq, size_t n, uint16_t *out);
 hipError_t launch_read_only(hipStream_t s, const void *buf, size_t bytes, uint32_t *sink);
 hipError_t launch_synth(hipStream_t s, const adsb_synth_cfg &cfg, int sample_type,
                         uint32_t channel, uint64_t first, size_t n, void *iq);

@@ -258,47 +258,33 @@ hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]
     return hipStreamSynchronize(s);
 }
 
-// ---- experiment ("magnitudes from an LDS table"): -DADSB_LUT_MAG=F ------------------------
-// F of a tile's phase-1 sweeps take floor(sqrt(n)) from a table in LDS keyed on n = I^2+Q^2 instead of v_sqrt_f32
-// (22 + 5 instead of 44 VALU instructions per 8 samples; the LDS pays a byte gather per sample).  The table covers
-// n < kLutN; a wave whose 8 x 64 samples of a sweep contain a larger n takes the arithmetic path for that sweep.
-// Needs the short tile (-DADSB_KRUN=32): every workgroup holds its own copy of the table.
-#ifndef ADSB_LUT_MAG
-#define ADSB_LUT_MAG 0
-#endif
-constexpr int kLutN = 16384;
-struct RootTable {
-    uint8_t v[kLutN];
-};
-constexpr RootTable make_root_table()
-{
-    RootTable t{};
-    uint32_t r = 0;
-    for (uint32_t n = 0; n < (uint32_t)kLutN; ++n) {
-        if ((r + 1) * (r + 1) <= n) ++r;
-        t.v[n] = (uint8_t)r;
-    }
-    return t;
-}
-#if ADSB_LUT_MAG
-__device__ const RootTable kRootTab __attribute__((aligned(16))) = make_root_table();
-#endif
-
 // ---- the fused tile kernel ------------------------------------------------------------------
 template <int ST> struct MagT;
 template <> struct MagT<ADSB_SAMPLE_I8> { typedef uint8_t type; };
 template <> struct MagT<ADSB_SAMPLE_I16> { typedef uint16_t type; };
 
-template <int ST> struct Lds {
+// ---- the nsq image (i8, kScanNsq): what phase 1 leaves in LDS for the gate and the slicer ------------------------
+// One dword per PAIR of samples half a tile apart: logical dword q in [0, kNsqLog) holds v(q) in its low half and
+// v(q + kNsqHalf) in its high half, v(k) = I_k^2 + Q_k^2 + 72 (<= 32840).  That pair is exactly what lane L's
+// two runs (offsets 32 L + o and kNsqHalf + 32 L + o) need in one VGPR at step o: the gate reads it as it is, no
+// unpacking.  Dwords kNsqHalf .. kNsqHalf+255 repeat samples as low halves that dwords 0..255 hold as high halves
+// (the halo of run A's last lanes).  Physical dword = q + 4 (q >> 6): four pad dwords per 64 put the 16-byte reads
+// of a ds_read_b128 lane group (lane L starts at 32 L) on sixteen different slots of the 64 banks.
+constexpr int kNsqBias = 72;                 // 9 * 8: (v >> 3) = (n >> 3) + 9 exactly
+constexpr int kNsqHalf = kTile / 2;          // 8192
+constexpr int kNsqLog = kNsqHalf + kHalo;    // logical dwords
+constexpr int nsq_phys(int q) { return q + 4 * (q >> 6); }
+constexpr int kNsqPhys = nsq_phys(kNsqLog);  // 8976 dwords = 35904 bytes
+static_assert(kNsqHalf % 64 == 0 && kHalo % 64 == 0 && kRun == 32, "nsq image: pads every 64 dwords, runs of 32");
+
+template <int ST, int SCAN = kScanRoot> struct Lds {
     typedef typename MagT<ST>::type mag_t;
-    static constexpr int kMagBytes = TileCfg<ST>::kMagT * (int)sizeof(mag_t);
-    static constexpr int kOffCand = kMagBytes;                 // 2 words per run: survivor bitmap
-    static constexpr int kOffList = kOffCand + 2 * kThreads * 8; // kListCap x u16
-    static constexpr int kOffSyn = kOffList + kListCap * 2;    // 112 x u32
-    static constexpr int kOffRes = kOffSyn + 112 * 4;          // 16 groups x 24 B record staging
-    static constexpr int kOffMisc = kOffRes + 16 * 24;         // 16 x u32
-    static constexpr int kOffTab = kOffMisc + 64;              // (ADSB_LUT_MAG builds, i8 only) floor(sqrt(n)), n < kLutN
-    static constexpr int kTotal = kOffTab + ((ADSB_LUT_MAG && ST == ADSB_SAMPLE_I8) ? kLutN : 0);
+    static constexpr bool kNsq = ST == ADSB_SAMPLE_I8 && SCAN == kScanNsq;
+    static constexpr int kMagBytes = kNsq ? kNsqPhys * 4 : TileCfg<ST>::kMagT * (int)sizeof(mag_t);
+    static constexpr int kOffCand = kMagBytes;                 // one word per run of 32 offsets: survivor bitmap
+    static constexpr int kOffList = kOffCand + 2 * kThreads * 4 * (TileCfg<ST>::kRunT / 32); // kListCap x u16
+    static constexpr int kOffMisc = kOffList + kListCap * 2;   // 16 x u32
+    static constexpr int kTotal = kOffMisc + 64;
 };
 
 // [phase:2 gate: unpack (helpers)]
@@ -404,59 +390,91 @@ __device__ __forceinline__ uint32_t slice_byte(const typename MagT<ST>::type *ma
     return byte;
 }
 
-// [phase:3 decode_candidate (tiles without slots only: cold)]
-template <int ST, bool NIBBLES = false>
-__device__ __forceinline__ bool decode_candidate(const typename MagT<ST>::type *mag, const uint32_t *syn, unsigned char *rec,
-                                                 const bool have, const uint32_t off, const uint64_t sample0,
-                                                 const uint32_t l, const uint32_t lane, const uint32_t *nib = nullptr)
+// [phase:3 slice_byte (nsq image)]
+// The same slice from the nsq image (i8, kScanNsq).  The reference compares truncated roots (demod.rs:106 on the
+// output of utils.rs:46-52): bit = floor(sqrt(x)) > floor(sqrt(y)) = (r * r > y) with r = floor(sqrt(x)) -- r * r is the
+// largest square <= x, so a square lies in (y, x] exactly when r * r > y.  One root per PAIR, survivors only
+// (224 samples per survivor ~ 0.1 roots per sample of the stream).  r = trunc(sqrtf(x + 0.5)) is exact for x <= 32768
+// (sqrt(x + 0.5) is >= 1.3e-3 from every integer there; v_sqrt_f32 errs by 1 ulp ~ 1e-5).
+// A 16-lane group works on one survivor at tile offset `off`; the group's window of 224 samples starts at logical
+// dword q + 16 of its half (half = off >= kNsqHalf).  Lane l reads the 16 consecutive samples of 16-aligned chunk
+// (q + 16) / 16 + l, moved up by one sample when q + 16 is odd (so that pairs never straddle two lanes), slices its
+// 8 pairs, and frame byte l is put together from the chunks of lanes l and l + 1 (one DPP row shift):
+// chunk bit j of lane l is frame bit 8 l + j - sh, sh = ((q + 16) % 16) / 2.  All 16 lanes of a group must be active.
+__device__ __forceinline__ uint32_t nsq_slice_byte(const uint32_t *img, const uint32_t off, const uint32_t l)
+{
+    const uint32_t half = off >= (uint32_t)kNsqHalf ? 1u : 0u;
+    const uint32_t base = off - half * (uint32_t)kNsqHalf + 16u; // logical dword of the first data sample
+    const uint32_t e = base & 15u, par = e & 1u, sh = e >> 1;
+    const uint32_t v = (base >> 4) + l;                            // this lane's 16-sample chunk
+    const uint32_t a1 = 16u * v + 4u * (v >> 2) + par;            // physical dword of its first sample
+    // its last sample sits behind a pad when the chunk ends a 64-block and was moved up by one
+    const uint32_t a2 = a1 + 15u + (((v & 3u) == 3u ? 4u : 0u) & (0u - par));
+    uint32_t d[16];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) d[j] = img[a1 + j];
+    d[15] = img[a2];
+    // (x, y) of a pair into one register: x in the low half, y in the high half (selectors 0-3: 2nd operand)
+    const uint32_t sel = half ? 0x07060302u : 0x05040100u;
+    uint32_t w[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        w[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], sel);
+        const float fx = (float)(w[j] & 0xFFFFu) - ((float)kNsqBias - 0.5f); // n + 0.5
+        const uint32_t r = (uint32_t)__builtin_amdgcn_sqrtf(fx);
+        r2[j] = __umul24(r, r) + (uint32_t)kNsqBias; // (r <= 181; one v_mad_u32_u24)
+    }
+    // bit j = r2 > y, MSB first: one SDWA compare per pair into its own SGPR pair, then chunk = chunk + chunk +
+    // carry-in per pair (v_addc): no v_cndmask.  All eight compares come first: gfx950 wants 2 wait states between a
+    // VALU writing an SGPR and a VALU reading it, and hipcc pads nothing inside asm.
+    uint32_t chunk = 0;
+    uint64_t m0, m1, m2, m3, m4, m5, m6, m7;
+    asm("v_cmp_gt_u32_sdwa %1, %9, %17 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_cmp_gt_u32_sdwa %2, %10, %18 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_cmp_gt_u32_sdwa %3, %11, %19 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_cmp_gt_u32_sdwa %4, %12, %20 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_cmp_gt_u32_sdwa %5, %13, %21 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_cmp_gt_u32_sdwa %6, %14, %22 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_cmp_gt_u32_sdwa %7, %15, %23 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_cmp_gt_u32_sdwa %8, %16, %24 src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %4\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %5\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %6\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %7\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %8"
+        : "+v"(chunk), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+        : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]), "v"(r2[4]), "v"(r2[5]), "v"(r2[6]), "v"(r2[7]),
+          "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7])
+        : "vcc");
+    const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)chunk, 0x101 /* row_shl:1 */, 0xF, 0xF, true);
+    return (((chunk << 8) | next) >> (8u - sh)) & 0xFFu;
+}
+
+// [phase:3 count_candidate (tiles without slots only: cold)]
+// Slot-store overflow (pathological input): the host re-plans from exact counts, so such a tile's
+// survivors are decoded in place only to be COUNTED.  A 16-lane group, one lane per frame byte (`byte` = this
+// lane's sliced byte, lanes 14/15 contribute nothing): syndrome = XOR of kSyn over the set bits; valid when it is
+// zero or the syndrome of one of the 88 data bits (crc.rs:49-65).  Returns the verdict on every lane of the group.
+__device__ __forceinline__ bool count_candidate(const bool have, const uint32_t byte, const uint32_t l, const uint32_t lane)
 {
     const uint32_t lb = l < 14 ? l : 13;
-    uint32_t byte = slice_byte<ST>(mag, off, lb);
-    // syndrome = XOR of table entries of the set bits, over the 14 bytes
     uint32_t s = 0;
-    const uint32_t *sy = syn + 8 * lb;
-    if (NIBBLES) {
-        // nib[(2 lb + h) * 16 + v] = XOR of the syndromes of the bits set in nibble v (h = 0: bits 7..4):
-        // two LDS reads and one XOR instead of eight reads and sixteen VALU instructions
-        const uint32_t e = nib[(2 * lb) * 16 + (byte >> 4)] ^ nib[(2 * lb + 1) * 16 + (byte & 15u)];
-        s = l < 14 ? e : 0u;
-    } else {
-        const int sb = (int)(l < 14 ? byte : 0u);
+    const uint32_t *sy = kSyn.v + 8 * lb;
+    const int sb = (int)(l < 14 ? byte : 0u);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
-    }
+    for (int k = 0; k < 8; ++k) s ^= sy[k] & (uint32_t)((sb << (24 + k)) >> 31); // mask = -bit k (MSB first)
     s = row16_xor(s);
-    // single-bit repair: only the 88 data bits can match (crc.rs:49-65)
     int found = -1;
     if (s != 0 && l < 11) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) found = (sy[k] == s) ? k : found;
     }
     const unsigned long long fm = __ballot(found >= 0);
-    const uint32_t gsh = (lane & 48u);
-    const uint32_t gbits = (uint32_t)(fm >> gsh) & 0xFFFFu;
-    const bool valid = have && (s == 0 || gbits != 0);
-    uint32_t status = 0xFFu, fixed = 0xFFu;
-    if (valid) {
-        status = (s == 0) ? 0u : 1u;
-        if (s != 0) {
-            const uint32_t fl = __builtin_ctz(gbits);
-            const int fk = __shfl(found, (int)fl, 16);
-            fixed = 8 * fl + (uint32_t)fk;
-            if (l == fl) byte ^= 0x80u >> fk;
-        }
-    }
-    if (have) {
-        if (l < 14) rec[8 + l] = (unsigned char)byte;
-        if (l == 14) rec[22] = (unsigned char)status;
-        if (l == 15) rec[23] = (unsigned char)fixed;
-        if (l == 0) {
-            const uint64_t o64 = sample0 + off;
-            reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)o64;
-            reinterpret_cast<uint32_t *>(rec)[1] = (uint32_t)(o64 >> 32);
-        }
-    }
-    return valid;
+    const uint32_t gbits = (uint32_t)(fm >> (lane & 48u)) & 0xFFFFu;
+    return have && (s == 0 || gbits != 0);
 }
 
 // [phase:end]
@@ -521,6 +539,55 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
 #define ADSB_GATE_GROUP 1 // steps per wave-uniform test in demod_tiles (see gate_phase)
 #endif
 
+// survivor bitmap words -> the lane's survivors appended (unordered) to the LDS list; shared by both gates
+template <int RUN, int NT>
+__device__ __forceinline__ void gate_collect(uint32_t *candA, uint32_t *candB, uint16_t *list, uint32_t *count,
+                                             const uint32_t tid, const uint32_t n_valid)
+{
+    constexpr int WPR = RUN / 32;
+    const uint32_t sa = tid * RUN, sb = (tid + NT) * RUN;
+    const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
+    uint32_t words[2 * WPR];
+    uint32_t nz = 0, c = 0;
+#pragma unroll
+    for (int k = 0; k < WPR; ++k) {
+        words[k] = candA[k];
+        words[WPR + k] = candB[k];
+    }
+    if (n_valid < (uint32_t)(2 * NT * RUN)) { // (wave-uniform) the ragged last tile of a channel
+#pragma unroll
+        for (int k = 0; k < WPR; ++k) {
+            const uint32_t la = va > 32u * k ? va - 32u * k : 0u, lb = vb > 32u * k ? vb - 32u * k : 0u;
+            words[k] &= la >= 32u ? 0xFFFFFFFFu : ((1u << la) - 1u);
+            words[WPR + k] &= lb >= 32u ? 0xFFFFFFFFu : ((1u << lb) - 1u);
+            candA[k] = words[k]; // the dense path of phase 3 reads the bitmap itself
+            candB[k] = words[WPR + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * WPR; ++k) {
+        nz |= words[k];
+        c += __builtin_popcount(words[k]);
+    }
+    // Survivors are rare (a handful per tile): the few lanes that have any append their offsets,
+    // unordered, to the list (ordering happens later).  The bitmap above is only read if there
+    // turn out to be more than kSparseCap.
+    if (nz) {
+        uint32_t pos = atomicAdd(count, c);
+#pragma unroll
+        for (int k = 0; k < 2 * WPR; ++k) {
+            uint32_t bits = words[k];
+            const uint32_t base = (k < WPR ? sa : sb) + (k % WPR) * 32;
+            while (bits) {
+                const uint32_t b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (pos < (uint32_t)kSparseCap) list[pos] = (uint16_t)(base + b);
+                ++pos;
+            }
+        }
+    }
+}
+
 // ---- the gate (phase 2 of both tile kernels) --------------------------------------------------
 // Preamble + DF17 ordering test (demod.rs:17-57) for the 2 x kRun offsets this lane owns:
 // run A = offsets [tid*RUN, +RUN), run B = [(tid+NT)*RUN, +RUN) of the tile whose magnitudes
@@ -545,9 +612,7 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
     uint32_t *candA = cand + WPR * tid, *candB = cand + WPR * (tid + NT);
 #pragma unroll
     for (int k = 0; k < WPR; ++k) candA[k] = candB[k] = 0u;
-    // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98)
-    const uint32_t sa = tid * RUN, sb = (tid + NT) * RUN;
-    const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
+    // (offsets at or beyond n_valid do not exist in the reference loop, adsb.rs:98: masked out in gate_collect)
     constexpr int kGran = (RUN + 26 + SPG - 1) / SPG + 1; // granules a run may touch
     const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * RUN);
     const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + NT) * RUN);
@@ -645,45 +710,7 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
 #if ADSB_ABL_NOCMP
     if (abl_acc == 0x12345678u) atomicOr(candA, 1u);
 #endif
-    uint32_t words[2 * WPR];
-    uint32_t nz = 0, c = 0;
-#pragma unroll
-    for (int k = 0; k < WPR; ++k) {
-        words[k] = candA[k];
-        words[WPR + k] = candB[k];
-    }
-    if (n_valid < (uint32_t)(2 * NT * RUN)) { // (wave-uniform) the ragged last tile of a channel
-#pragma unroll
-        for (int k = 0; k < WPR; ++k) {
-            const uint32_t la = va > 32u * k ? va - 32u * k : 0u, lb = vb > 32u * k ? vb - 32u * k : 0u;
-            words[k] &= la >= 32u ? 0xFFFFFFFFu : ((1u << la) - 1u);
-            words[WPR + k] &= lb >= 32u ? 0xFFFFFFFFu : ((1u << lb) - 1u);
-            candA[k] = words[k]; // the dense path of phase 3 reads the bitmap itself
-            candB[k] = words[WPR + k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 2 * WPR; ++k) {
-        nz |= words[k];
-        c += __builtin_popcount(words[k]);
-    }
-    // Survivors are rare (a handful per tile): the few lanes that have any append their offsets,
-    // unordered, to the list (ordering happens later).  The bitmap above is only read if there
-    // turn out to be more than kSparseCap.
-    if (nz) {
-        uint32_t pos = atomicAdd(count, c);
-#pragma unroll
-        for (int k = 0; k < 2 * WPR; ++k) {
-            uint32_t bits = words[k];
-            const uint32_t base = (k < WPR ? sa : sb) + (k % WPR) * 32;
-            while (bits) {
-                const uint32_t b = __builtin_ctz(bits);
-                bits &= bits - 1;
-                if (pos < (uint32_t)kSparseCap) list[pos] = (uint16_t)(base + b);
-                ++pos;
-            }
-        }
-    }
+    gate_collect<RUN, NT>(candA, candB, list, count, tid, n_valid);
 }
 
 // [phase:end]
@@ -756,79 +783,211 @@ __device__ __forceinline__ bool magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIt
     return ST == ADSB_SAMPLE_I16 && __builtin_amdgcn_ballot_w64(((mx & 0xFFFFu) >= 0x7C00u) || ((mx >> 16) >= 0x7C00u)) != 0;
 }
 
-#if ADSB_LUT_MAG
-// i8 phase 1 with F table sweeps: sweeps [0, kIters-1-F) by arithmetic, then (the table is in LDS by now: barrier)
-// sweeps [kIters-1-F, kIters-1) through the table, the short last sweep by arithmetic.
-template <int MAGMODE>
-__device__ __forceinline__ void magnitudes_to_lds_lut(const u32x4 (&raw)[P1<ADSB_SAMPLE_I8>::kIters], uint8_t *mag,
-                                                      const uint8_t *tab, const u32x4 (&tb)[kLutN / (kThreads * 16)], uint32_t tid)
+// [phase:1 nsq (loads, dots, stores)]
+// ---- phase 1 of the nsq scan: raw i8 IQ -> the nsq image --------------------------------------------------------
+// One sweep of a lane = 16 bytes at sample q0 (eight "A" samples, low halves) and 16 bytes at sample q0 + kNsqHalf
+// (eight "B" samples, high halves) -> eight packed dwords -> two ds_write_b128.  kNsqIters sweeps of the workgroup
+// cover the image; the last one is the 256-dword halo (lanes 0-31 only).
+constexpr int kNsqIters = (kNsqLog + kThreads * 8 - 1) / (kThreads * 8);
+constexpr int kNsqFull = kNsqLog / (kThreads * 8);  // sweeps every lane takes part in
+constexpr int kNsqTail = kNsqLog % (kThreads * 8);  // logical dwords of the last, partial sweep (the halo: 256)
+static_assert(kNsqIters - kNsqFull <= 1 && kNsqTail % 8 == 0, "at most one partial sweep of whole lanes");
+
+__device__ __forceinline__ void nsq_issue_loads(const DemodArgs &p, const TilePos &tp, uint32_t tid,
+                                                u32x4 (&ra)[kNsqIters], u32x4 (&rb)[kNsqIters])
 {
-    constexpr int ST = ADSB_SAMPLE_I8;
-    constexpr int kIt = P1<ST>::kIters;
-    constexpr int F = ADSB_LUT_MAG < kIt - 1 ? ADSB_LUT_MAG : kIt - 1;
-    constexpr int kFirst = kIt - 1 - F;
-    // the table: global (L2) -> registers (issued before the tile's loads) -> LDS
+    __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<2, kMag>(p, tp, true);
+    // (the sweep's constant goes into the SGPR offset, which the descriptor's bounds check covers:
+    // tools/ubench/soffset_probe.hip; reads past the channel end return zeros)
 #pragma unroll
-    for (int j = 0; j < kLutN / (kThreads * 16); ++j)
-        reinterpret_cast<u32x4 *>(const_cast<uint8_t *>(tab))[j * kThreads + tid] = tb[j];
-#pragma unroll
-    for (int it = 0; it < kFirst; ++it) {
-        const uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
-        uint32_t lo, hi;
-        mags8_i8<MAGMODE>(raw[it], lo, hi);
-        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+    for (int it = 0; it < kNsqFull; ++it) {
+        ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16), ADSB_LOAD_AUX);
+        rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16) + 2 * kNsqHalf, ADSB_LOAD_AUX);
     }
-    __syncthreads();
-    uint32_t r[F > 0 ? F : 1][8];
-    bool slow[F > 0 ? F : 1];
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        int n[8];
-        dot4x8_sacc(raw[kFirst + f], 0, n);
-        uint32_t m = (uint32_t)n[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) m = m > (uint32_t)n[k] ? m : (uint32_t)n[k]; // (v_max3_u32 x 3 + v_max_u32)
-        slow[f] = __builtin_amdgcn_ballot_w64(m >= (uint32_t)kLutN) != 0;
-        if (__builtin_expect(slow[f], 0)) {
-            mags8_i8<MAGMODE>(raw[kFirst + f], r[f][0], r[f][1]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r[f][k] = tab[n[k]];
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        const uint32_t s = (uint32_t)(kFirst + f) * (kThreads * 8) + tid * 8;
-        uint32_t lo = r[f][0], hi = r[f][1];
-        if (!slow[f]) {
-            lo = r[f][0] | (r[f][1] << 8) | (r[f][2] << 16) | (r[f][3] << 24);
-            hi = r[f][4] | (r[f][5] << 8) | (r[f][6] << 16) | (r[f][7] << 24);
-        }
-        *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
-    }
-    { // the short last sweep (halo only)
-        constexpr int it = kIt - 1;
-        const uint32_t wave_s0 = __builtin_amdgcn_readfirstlane(tid & ~63u) * 8;
-        if ((uint32_t)it * (kThreads * 8) + wave_s0 < (uint32_t)TileCfg<ST>::kMagT) {
-            const uint32_t s = (uint32_t)it * (kThreads * 8) + tid * 8;
-            uint32_t lo, hi;
-            mags8_i8<MAGMODE>(raw[it], lo, hi);
-            if (s < (uint32_t)TileCfg<ST>::kMagT) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
-        }
+    if (kNsqTail && __builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kNsqTail) { // (whole waves past the halo skip it)
+        ra[kNsqFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kNsqFull * (kThreads * 16), ADSB_LOAD_AUX);
+        rb[kNsqFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kNsqFull * (kThreads * 16) + 2 * kNsqHalf, ADSB_LOAD_AUX);
     }
 }
-#endif
+
+// 8 A samples + 8 B samples -> 8 dwords (B's v << 16) | A's v, v = I^2 + Q^2 + 72.
+//   A: v_and (the sample's two bytes) + v_dot4_i32_i8 accumulating onto the SGPR constant 0x00480048 (the bias of
+//      both halves at once);
+//   B: v_perm to the i16 pair (I * 256, Q * 256) + v_dot2_i32_i16 accumulating onto A's result: (I^2 + Q^2) << 16.
+//      (n = 32768, I = Q = -128, wraps to the right bits.)
+// 2 VALU per sample, packing included.  gfx950 wants 3 wait states between a DOT and a different VALU reading its
+// result and hipcc pads nothing inside asm: the dot2 reads its dot4 eight instructions later, and the block ends in
+// s_nop 2.
+__device__ __forceinline__ void nsq_pack16(u32x4 a, u32x4 b, uint32_t (&d)[8])
+{
+    const uint32_t a0 = a.x & 0xFFFFu, a1 = a.x & 0xFFFF0000u, a2 = a.y & 0xFFFFu, a3 = a.y & 0xFFFF0000u,
+                   a4 = a.z & 0xFFFFu, a5 = a.z & 0xFFFF0000u, a6 = a.w & 0xFFFFu, a7 = a.w & 0xFFFF0000u;
+    // bytes [0, I, 0, Q] of the even / odd sample of a dword (selector 0x0C = a zero byte)
+    const uint32_t h0 = __builtin_amdgcn_perm(b.x, b.x, 0x010C000Cu), h1 = __builtin_amdgcn_perm(b.x, b.x, 0x030C020Cu),
+                   h2 = __builtin_amdgcn_perm(b.y, b.y, 0x010C000Cu), h3 = __builtin_amdgcn_perm(b.y, b.y, 0x030C020Cu),
+                   h4 = __builtin_amdgcn_perm(b.z, b.z, 0x010C000Cu), h5 = __builtin_amdgcn_perm(b.z, b.z, 0x030C020Cu),
+                   h6 = __builtin_amdgcn_perm(b.w, b.w, 0x010C000Cu), h7 = __builtin_amdgcn_perm(b.w, b.w, 0x030C020Cu);
+    const uint32_t bias2 = (uint32_t)kNsqBias * 0x00010001u;
+    asm("v_dot4_i32_i8 %0, %8, %12, %28\n\t"
+        "v_dot4_i32_i8 %1, %8, %13, %28\n\t"
+        "v_dot4_i32_i8 %2, %9, %14, %28\n\t"
+        "v_dot4_i32_i8 %3, %9, %15, %28\n\t"
+        "v_dot4_i32_i8 %4, %10, %16, %28\n\t"
+        "v_dot4_i32_i8 %5, %10, %17, %28\n\t"
+        "v_dot4_i32_i8 %6, %11, %18, %28\n\t"
+        "v_dot4_i32_i8 %7, %11, %19, %28\n\t"
+        "v_dot2_i32_i16 %0, %20, %20, %0\n\t"
+        "v_dot2_i32_i16 %1, %21, %21, %1\n\t"
+        "v_dot2_i32_i16 %2, %22, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %23, %23, %3\n\t"
+        "v_dot2_i32_i16 %4, %24, %24, %4\n\t"
+        "v_dot2_i32_i16 %5, %25, %25, %5\n\t"
+        "v_dot2_i32_i16 %6, %26, %26, %6\n\t"
+        "v_dot2_i32_i16 %7, %27, %27, %7\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7),
+          "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(h4), "v"(h5), "v"(h6), "v"(h7), "s"(bias2));
+}
+
+// raw IQ -> the nsq image.  Returns (wave-uniform) whether this wave saw a value that is not an ordered f16 bit
+// pattern: v >= 0x7C00, i.e. |I| and |Q| both >= 125 (nine values of n, 31752 .. 32768).  The running
+// v_pk_minimum3_f16 finds them all: 0x7C01..0x7FFF are NaNs, which minimum3 propagates, 0x8048 (n = 32768) is a
+// negative number, and 0x7C00 (+infinity, which a minimum would not see) is no sum of two squares of i8 values.
+__device__ __forceinline__ bool nsq_image_to_lds(const u32x4 (&ra)[kNsqIters], const u32x4 (&rb)[kNsqIters], uint32_t *img, uint32_t tid)
+{
+    uint32_t lo = 0x7BFF7BFFu; // largest finite pattern
+    const uint32_t q_t = tid * 8;
+    uint32_t *dst = img + q_t + 4 * (q_t >> 6);
+    auto sweep = [&](const int it, const bool store) {
+        uint32_t d[8];
+        nsq_pack16(ra[it], rb[it], d);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) lo = pkmin3<true>(lo, d[k], d[k + 1]);
+        if (store) { // (8 kThreads is a multiple of 64: the sweep is a constant offset)
+            u32x4 *w = reinterpret_cast<u32x4 *>(dst + nsq_phys(it * kThreads * 8));
+            w[0] = u32x4{d[0], d[1], d[2], d[3]};
+            w[1] = u32x4{d[4], d[5], d[6], d[7]};
+        }
+    };
+#pragma unroll
+    for (int it = 0; it < kNsqFull; ++it) sweep(it, true);
+    if (kNsqTail && __builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kNsqTail) sweep(kNsqFull, q_t < (uint32_t)kNsqTail);
+    return __builtin_amdgcn_ballot_w64(((lo & 0xFFFFu) >= 0x7C00u) || ((lo >> 16) >= 0x7C00u)) != 0;
+}
+
+// [phase:2 nsq gate: set-up]
+// ---- the gate on the nsq image ------------------------------------------------------------------------------------
+// The reference orders truncated roots s(.) = floor(sqrt(.)) (demod.rs:27-36, 48-54 on utils.rs:46-52): pass when
+// s(a) >= s(b), a = the smallest "high" n, b = the largest "low" n (s is monotone, so the minimum / maximum of the
+// roots are the roots of the minimum / maximum).  On n itself:  a >= b passes outright;  a < b passes only if
+// s(a) = s(b), which forces b - a <= 2 s(a) <= 2 sqrt(a) <= a / 8 + 8 (AM-GM).  So with the biased values v = n + 72
+//     b' <= t(a'),   t(x) = x + (x >> 3)          [ = n_a + (n_a >> 3) + 9 + 72 ]
+// is an exact SUPERSET test in two packed instructions; lanes that pass it for the preamble AND the DF17 group are
+// survivors at once when a' >= b' in both, and only the rest (a < b inside the band: a handful per million offsets)
+// take two roots per group in a cold block.  Per step (two offsets) the common path is 3 three-input max, 2 min,
+// shift, add, 2 compares = 9 VALU on values that need no unpacking.
+// F16OK: every value of the tile is below 0x7C00, an ordered f16 pattern (v_pk_maximum3_f16 / v_pk_minimum3_f16);
+// otherwise pairs of integer v_pk_max_u16 / v_pk_min_u16.
+__device__ __forceinline__ uint32_t nsq_band(uint32_t x)
+{
+    const u16x2 v = __builtin_bit_cast(u16x2, x);
+    return __builtin_bit_cast(uint32_t, (u16x2)(v + (v >> 3)));
+}
+__device__ __forceinline__ uint32_t nsq_root(uint32_t v) // floor(sqrt(v - 72)), exact for v - 72 <= 32768
+{
+    return (uint32_t)__builtin_amdgcn_sqrtf((float)v - ((float)kNsqBias - 0.5f));
+}
+
+template <bool F16OK>
+__device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *cand, uint16_t *list, uint32_t *count,
+                                               const uint32_t tid, const uint32_t n_valid)
+{
+    constexpr int RUN = kRun, NT = kThreads;
+    uint32_t *candA = cand + tid, *candB = cand + (tid + NT);
+    *candA = 0u;
+    *candB = 0u;
+    // run A = offsets 32 tid + o, run B = kNsqHalf + 32 tid + o: logical dwords 32 tid + j, j < RUN + 26.  Physical:
+    // 32 tid + 4 (tid >> 1) for j < 32; the second half of an odd lane's reads lies behind the next pad.
+    const u32x4 *g0 = reinterpret_cast<const u32x4 *>(img + 32 * tid + 4 * (tid >> 1));
+    const u32x4 *g1 = g0 + 8 + (tid & 1u);
+    constexpr int kGran = (RUN + 26 + 3) / 4; // 15 granules of four pairs
+    constexpr int kAhead = 12;                // 48 pairs resident ahead of the current block
+    uint32_t N[kGran * 4];
+    auto fetch = [&](int g) {
+        const u32x4 x = g < 8 ? g0[g] : g1[g - 8];
+        N[4 * g] = x.x; N[4 * g + 1] = x.y; N[4 * g + 2] = x.z; N[4 * g + 3] = x.w;
+    };
+#pragma unroll
+    for (int g = 0; g < kAhead; ++g) fetch(g);
+    //   N[j]  pair of values               H2[j] = min(N[j], N[j+2])
+    //   W3[j] = max(N[j..j+2])             F[j]  = max(N[j], W3[j+2], N[j+5])
+    // highs of offset o: min(H2[o], H2[o+7]);  lows: max(F[o+1], F[o+8], W3[o+13])
+    uint32_t H2[RUN + 8], W3[RUN + 16], F[RUN + 9];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
+#pragma unroll
+    for (int j = 3; j < 13; ++j) W3[j] = pkmax3<F16OK>(N[j], N[j + 1], N[j + 2]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) F[j] = pkmax3<F16OK>(N[j], W3[j + 2], N[j + 5]);
+
+    // [phase:2 nsq gate: steps]
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) {
+        if (o % 4 == 0) { // keep 48 pairs resident ahead of the block that starts here
+            const int g = o / 4 + kAhead;
+            if (g < kGran) fetch(g);
+        }
+        W3[o + 13] = pkmax3<F16OK>(N[o + 13], N[o + 14], N[o + 15]);
+        F[o + 8] = pkmax3<F16OK>(N[o + 8], W3[o + 10], N[o + 13]);           // lows 8,10,11,12,13
+        const uint32_t lo = pkmax3<F16OK>(F[o + 1], F[o + 8], W3[o + 13]);   // + 1,3,4,5,6 + 13,14,15
+        H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
+        const uint32_t hi = pkmin(H2[o], H2[o + 7]);                      // highs 0,2,7,9
+        const uint32_t t = nsq_band(hi);
+        const bool pa = (uint16_t)t >= (uint16_t)lo;
+        const bool pb = (t >> 16) >= (lo >> 16);
+        // [phase:2 nsq gate: DF17 (cold)]
+        // wave-uniform tests (scalar branches, no exec juggling): a block is entered by the whole wave when any
+        // lane needs it; its effects are masked by the lanes' own flags
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa | pb) != 0, 0)) {
+            // DF17 part of the gate (demod.rs:45-54), the same superset test
+            const uint32_t dh = pkmin3<F16OK>(pkmin3<F16OK>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
+            const uint32_t dl = pkmax3<F16OK>(pkmax3<F16OK>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
+            const uint32_t t2 = nsq_band(dh);
+            bool sa = pa & ((uint16_t)t2 >= (uint16_t)dl);
+            bool sb = pb & ((t2 >> 16) >= (dl >> 16));
+            if (__builtin_amdgcn_ballot_w64(sa | sb) != 0) {
+                // inside both bands.  Exact at once where both groups are ordered on n itself ...
+                const bool ea = ((uint16_t)hi >= (uint16_t)lo) & ((uint16_t)dh >= (uint16_t)dl);
+                const bool eb = ((hi >> 16) >= (lo >> 16)) & ((dh >> 16) >= (dl >> 16));
+                // [phase:2 nsq gate: roots (cold)]
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((sa & !ea) | (sb & !eb)) != 0, 0)) {
+                    // ... the rest by the truncated roots themselves (utils.rs:46-52): ties after truncation pass
+                    const bool ra = nsq_root(hi & 0xFFFFu) >= nsq_root(lo & 0xFFFFu) && nsq_root(dh & 0xFFFFu) >= nsq_root(dl & 0xFFFFu);
+                    const bool rb = nsq_root(hi >> 16) >= nsq_root(lo >> 16) && nsq_root(dh >> 16) >= nsq_root(dl >> 16);
+                    sa = sa && (ea || ra);
+                    sb = sb && (eb || rb);
+                }
+                // (offsets at or beyond n_valid are masked out of the bitmap words afterwards, in the one tile per
+                // channel that has any)
+                uint32_t bit = 1u << o;
+                asm("" : "+v"(bit)); // one v_mov for both stores
+                if (sa) atomicOr(candA, bit);
+                if (sb) atomicOr(candB, bit);
+            }
+        }
+    }
+    // [phase:2 nsq gate: survivor list]
+    gate_collect<RUN, NT>(candA, candB, list, count, tid, n_valid);
+}
 
 // [phase:end]
-#ifndef ADSB_WAVES_PER_SIMD
-#define ADSB_WAVES_PER_SIMD (kRun >= 64 ? 4 : (kRun >= 48 ? 5 : 6))
-#endif
-
-// demod_tiles: one workgroup = one tile; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU (the
-// tile's magnitudes take 33 KB of LDS) and starts the next tile as soon as one retires, which staggers the phases of
+// demod_tiles: one workgroup = one tile; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU (a
+// tile's image takes 33-36 KB of LDS) and starts the next tile as soon as one retires, which staggers the phases of
 // co-resident workgroups.  Per tile:
-//   phase 1  17 x 16 bytes per lane of raw IQ, all in flight at once, become magnitudes in LDS;      ... barrier
-//   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase);                                ... barrier
+//   phase 1  the tile's raw IQ (16-byte loads, all in flight at once) becomes the LDS image: i8/kScanNsq: pairs of
+//            biased I^2+Q^2; i8/kScanRoot (A/B kernel) and CS16: floor(sqrt) magnitudes;                ... barrier
+//   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase_nsq / gate_phase);                 ... barrier
 //   phase 3  every survivor gets a frame slot, its offset and its 14 sliced bytes; CRC-24, repair and ordering are
 //            finish_candidates' (below).
 // Measured alternatives: persistent workgroups drawing tiles from per-XCD ticket counters with
@@ -836,25 +995,26 @@ __device__ __forceinline__ void magnitudes_to_lds_lut(const u32x4 (&raw)[P1<ADSB
 // tile in ~10 % more VALU instructions (loop-carried registers, SGPR spills) and come out 7 % slower: in-kernel cycle
 // stamps (tools/gpu/tile_stamps.py) show the SIMDs VALU-saturated while any three of the four slots compute, so
 // filling the gaps buys nothing -- the instruction count is what bounds this kernel.
-template <int ST, int MAGMODE>
-__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SIMD : (kRunI16 >= 64 ? 2 : 4))) void demod_tiles(DemodArgs p)
+template <int ST, int MAGMODE, int SCAN>
+__global__ __launch_bounds__(kThreads, 4) void demod_tiles(DemodArgs p)
 {
-    typedef Lds<ST> L;
+    typedef Lds<ST, SCAN> L;
     typedef TileCfg<ST> TC; // tile length of this sample type
     typedef typename L::mag_t mag_t;
+    constexpr bool NSQ = L::kNsq;
+    static_assert(kThreads / 64 <= 4, "misc[4 + wave] must stay below misc[8]");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
     mag_t *mag = reinterpret_cast<mag_t *>(smem);
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem); // (nsq) the same bytes as pairs of biased squared magnitudes
     uint32_t *cand = reinterpret_cast<uint32_t *>(smem + L::kOffCand);
     uint16_t *list = reinterpret_cast<uint16_t *>(smem + L::kOffList);
-    uint32_t *syn = reinterpret_cast<uint32_t *>(smem + L::kOffSyn);
-    unsigned char *res = smem + L::kOffRes;
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
 
-    if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
+    if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
 #if ADSB_TILE_STAMPS
     unsigned long long ts_prev = 0;
     uint32_t ts_seg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -869,19 +1029,12 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         const uint32_t n_valid = tp.n_valid;
 
         // [phase:1 magnitude (loads, stores)]
-        // ---- phase 1: raw IQ -> magnitudes in LDS; the loads go out before anything else ----------------------
-        u32x4 raw[P1<ST>::kIters];
-#if ADSB_LUT_MAG
-        u32x4 tb[kLutN / (kThreads * 16)];
-        if (ST == ADSB_SAMPLE_I8) {
-#pragma unroll
-            for (int j = 0; j < kLutN / (kThreads * 16); ++j)
-                tb[j] = reinterpret_cast<const u32x4 *>(kRootTab.v)[j * kThreads + tid];
-        }
-#endif
-        issue_tile_loads<ST>(p, tp, true, tid, raw);
+        // ---- phase 1: raw IQ -> the LDS image; the loads go out before anything else ----------------------------
+        u32x4 raw[NSQ ? 1 : P1<ST>::kIters];
+        u32x4 raw_a[NSQ ? kNsqIters : 1], raw_b[NSQ ? kNsqIters : 1];
+        if constexpr (NSQ) nsq_issue_loads(p, tp, tid, raw_a, raw_b);
+        else issue_tile_loads<ST>(p, tp, true, tid, raw);
         TSTAMP(0); // prologue, loads issued
-        if (tid < 112) syn[tid] = kSyn.v[tid];
         if (tid == 0) {
             misc[8] = 0;  // valid-frame counter
             misc[12] = 0; // survivor counter
@@ -897,33 +1050,34 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
         TSTAMP(6);                                       // ... as its own segment
 #endif
-#if ADSB_LUT_MAG
-        bool wave_big = false;
-        if constexpr (ST == ADSB_SAMPLE_I8) magnitudes_to_lds_lut<MAGMODE>(raw, mag, smem + L::kOffTab, tb, tid);
+        bool wave_big;
+        if constexpr (NSQ) wave_big = nsq_image_to_lds(raw_a, raw_b, img, tid);
         else wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
-#else
-        const bool wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
-#endif
-        if (ST == ADSB_SAMPLE_I16 && lane == 0) misc[4 + wave] = wave_big ? 1u : 0u; // (every wave writes its own word)
+        if ((NSQ || ST == ADSB_SAMPLE_I16) && lane == 0) misc[4 + wave] = wave_big ? 1u : 0u; // (every wave writes its own word)
         TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
         TSTAMP(2); // barrier
 #if ADSB_ABL_PHASES < 2
         // (keeps the LDS stores of phase 1 alive; never true for real data)
-        if (mag[tid * 64] == 0xFD && mag[tid * 64 + 1] == 0xFE && n_valid == 7) misc[12] = 1;
+        if (smem[tid * 64] == 0xFD && smem[tid * 64 + 1] == 0xFE && n_valid == 7) misc[12] = 1;
 #else
 
         // [phase:2 gate: call]
         // ---- phase 2: preamble + DF17 gate, two runs per lane, packed u16x2 --------------------
-        if (ST == ADSB_SAMPLE_I16) {
-            // CS16: the 3-input f16 gate (8 instead of 11 instructions per step) whenever every magnitude of the tile
-            // is an ordered f16 pattern -- any signal below 2/3 of full scale; the integer gate otherwise
+        if constexpr (NSQ || ST == ADSB_SAMPLE_I16) {
+            // the 3-input f16 gate whenever every value of the tile is an ordered f16 pattern (nsq: unless some sample
+            // has |I| and |Q| >= 125; CS16: any signal below 2/3 of full scale); the integer gate otherwise
             uint32_t any_big = 0;
 #pragma unroll
             for (int w = 0; w < kThreads / 64; ++w) any_big |= misc[4 + w];
             const bool big = any_big != 0; // (workgroup-uniform)
-            if (!big) gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, true>(mag, cand, list, &misc[12], tid, n_valid);
-            else gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, false>(mag, cand, list, &misc[12], tid, n_valid);
+            if constexpr (NSQ) {
+                if (!big) gate_phase_nsq<true>(img, cand, list, &misc[12], tid, n_valid);
+                else gate_phase_nsq<false>(img, cand, list, &misc[12], tid, n_valid);
+            } else {
+                if (!big) gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, true>(mag, cand, list, &misc[12], tid, n_valid);
+                else gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, false>(mag, cand, list, &misc[12], tid, n_valid);
+            }
         } else {
             gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
         }
@@ -985,7 +1139,9 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                 const uint32_t ci = r + g;
                 const bool have = ci < ncl; // uniform within the 16-lane group
                 const uint32_t off = have ? list[ci] : 0u;
-                const uint32_t byte = slice_byte<ST>(mag, off, l < 14 ? l : 13);
+                uint32_t byte;
+                if constexpr (NSQ) byte = nsq_slice_byte(img, off, l);
+                else byte = slice_byte<ST>(mag, off, l < 14 ? l : 13);
                 if (have) {
                     unsigned char *rec = reinterpret_cast<unsigned char *>(p.slots + (size_t)slot0 + ci);
                     const uint64_t o64 = abs0 + off;
@@ -999,7 +1155,8 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         } else {
             if (tid == 0) {
                 const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
-                misc[9] = (b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
+                // (pool_off: test knob, adsb_debug_pool_limit -- every tile over its quota loses its slots)
+                misc[9] = (!p.pool_off && b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
             }
             __syncthreads();
             base_slot = misc[9];
@@ -1031,8 +1188,10 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
                         const uint32_t ci = r + g;
                         const bool have = ci < ncl; // uniform within the 16-lane group
                         const uint32_t off = have ? list[ci] : 0u;
-                        unsigned char *rec = res + g * 24;
-                        const bool valid = decode_candidate<ST>(mag, syn, rec, have, off, abs0, l, lane);
+                        uint32_t byte;
+                        if constexpr (NSQ) byte = nsq_slice_byte(img, off, l);
+                        else byte = slice_byte<ST>(mag, off, l < 14 ? l : 13);
+                        const bool valid = count_candidate(have, byte, l, lane);
                         if (valid && l == 0) atomicAdd(&misc[8], 1u);
                     }
                 }
@@ -1059,7 +1218,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 ? ADSB_WAVES_PER_SI
         }
     }
     // [phase:end]
-    if (MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
+    if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
 // ---- CRC-24 + single-bit repair of the sliced survivors (demod.rs:71-81; crc.rs:10-65) --------------------------
@@ -1314,35 +1473,23 @@ static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &
     dim3 grid(grid_x), block(kThreads);
     if (ST == ADSB_SAMPLE_I16) mag_mode = 0; // the CS16 magnitude chain does not depend on the converter's rounding
     switch (mag_mode) {
-    case 0: hipExtLaunchKernelGGL((demod_tiles<ST, 0>), grid, block, 0, s, e0, e1, 0, a); break;
-    case 1: hipExtLaunchKernelGGL((demod_tiles<ST, ST == ADSB_SAMPLE_I8 ? 1 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
-    default: hipExtLaunchKernelGGL((demod_tiles<ST, ST == ADSB_SAMPLE_I8 ? 2 : 0>), grid, block, 0, s, e0, e1, 0, a); break;
+    case 0: hipExtLaunchKernelGGL((demod_tiles<ST, 0, kScanRoot>), grid, block, 0, s, e0, e1, 0, a); break;
+    case 1: hipExtLaunchKernelGGL((demod_tiles<ST, ST == ADSB_SAMPLE_I8 ? 1 : 0, kScanRoot>), grid, block, 0, s, e0, e1, 0, a); break;
+    default: hipExtLaunchKernelGGL((demod_tiles<ST, ST == ADSB_SAMPLE_I8 ? 2 : 0, kScanRoot>), grid, block, 0, s, e0, e1, 0, a); break;
     }
     return hipGetLastError();
 }
 
-// The streaming form of the i8 kernel (one persistent 1024-thread workgroup per CU, table-lookup magnitudes) is an
-// experiment that never beat demod_tiles at the bench size.  It lives in
-// tools/experimental/ and is compiled in only by `tools/build_variant.sh stream -DADSB_WITH_STREAM_KERNEL=1
-// -Itools/experimental`; the product build has one i8 kernel.
-#ifndef ADSB_WITH_STREAM_KERNEL
-#define ADSB_WITH_STREAM_KERNEL 0
-#endif
-#if ADSB_WITH_STREAM_KERNEL
-#include "adsb_stream_kernel.h"
-#else
-hipError_t launch_build_lut(hipStream_t, uint8_t *) { return hipErrorNotSupported; }
-#endif
-bool stream_kernel_built() { return ADSB_WITH_STREAM_KERNEL != 0; }
 bool tile_stamps_built() { return ADSB_TILE_STAMPS != 0; }
 
-hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
+hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, const DemodArgs &a,
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (a.tile_count == 0) return hipSuccess;
-#if ADSB_WITH_STREAM_KERNEL
-    if (sample_type == ADSB_SAMPLE_I8 && a.lut && a.stream_grid) return launch_demod_stream(s, a, a.stream_grid, e0, e1);
-#endif
+    if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
+        hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq>), dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
+        return hipGetLastError();
+    }
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);
     return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count, e0, e1);
 }
@@ -1615,6 +1762,35 @@ hipError_t launch_magnitudes(hipStream_t s, int sample_type, int mag_mode, const
     } else {
         hipLaunchKernelGGL((magnitudes_kernel<ADSB_SAMPLE_I8, 2>), grid, block, 0, s, iq, n, out);
     }
+    return hipGetLastError();
+}
+
+// nsq test hook: v = I^2 + Q^2 + 72 of n i8 samples through the scan kernel's own packing code (every group of 8
+// samples is packed once as the "A" AND the "B" operand: both halves must agree, else 0xFFFF is reported).
+__global__ void nsq_values_kernel(const void *iq, size_t n, uint16_t *out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t groups = (n + 7) / 8;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(iq) + g * 8;
+        uint16_t tmp[8];
+        for (int k = 0; k < 8; ++k) tmp[k] = (g * 8 + k < n) ? src[k] : (uint16_t)0;
+        u32x4 v;
+        v.x = tmp[0] | ((uint32_t)tmp[1] << 16);
+        v.y = tmp[2] | ((uint32_t)tmp[3] << 16);
+        v.z = tmp[4] | ((uint32_t)tmp[5] << 16);
+        v.w = tmp[6] | ((uint32_t)tmp[7] << 16);
+        uint32_t d[8];
+        nsq_pack16(v, v, d);
+        for (int k = 0; k < 8; ++k)
+            if (g * 8 + k < n) out[g * 8 + k] = (d[k] & 0xFFFFu) == (d[k] >> 16) ? (uint16_t)(d[k] & 0xFFFFu) : (uint16_t)0xFFFFu;
+    }
+}
+
+hipError_t launch_nsq_values(hipStream_t s, const void *iq, size_t n, uint16_t *out)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(nsq_values_kernel, dim3(1024), dim3(256), 0, s, iq, n, out);
     return hipGetLastError();
 }
 

@@ -150,11 +150,14 @@ class AdsbDemod:
         return self._lib.adsb_debug_mag_mode(self._h)
 
     @property
-    def kernel(self):
-        """'tiles' (demod_tiles: the product's only kernel) or 'stream' (the experimental streaming kernel of
-        tools/experimental/, present only in -DADSB_WITH_STREAM_KERNEL=1 builds and then chosen with
-        ADSB_KERNEL=stream at creation)."""
-        return "stream" if self._lib.adsb_debug_kernel(self._h) == 1 else "tiles"
+    def scan(self):
+        """'nsq' (the product's i8 scan kernel: gate on I^2+Q^2) or 'root' (floor(sqrt) per sample: CS16 always;
+        i8 when ADSB_SCAN=root was set at creation, for A/B measurements)."""
+        return "root" if self._lib.adsb_debug_scan(self._h) == 1 else "nsq"
+
+    def pool_limit(self, on=True):
+        """Test knob: the shared slot pool hands out nothing (tiles over their quota lose their slots)."""
+        L.check(self._lib.adsb_debug_pool_limit(self._h, 1 if on else 0), "adsb_debug_pool_limit")
 
     # -- behind the channel: tracker + CPR on the device (aircraft.rs, cpr.rs) ------------------------
     def track(self, seconds_per_sample=0.5e-6):
@@ -168,12 +171,6 @@ class AdsbDemod:
                                            len(acs), C.byref(nac)), "adsb_fetch_track")
         return pts[:npts.value].copy(), acs[:min(nac.value, len(acs))].copy()
 
-    def stamps(self):
-        """Diagnostic builds (-DADSB_STAMPS=1): 16 shader-cycle sums of workgroup 0, last launch."""
-        out = np.zeros(16, dtype=np.uint64)
-        L.check(self._lib.adsb_debug_stamps(self._h, out.ctypes.data), "adsb_debug_stamps")
-        return out
-
     def fused_pass_only(self, on=True):
         """Measurement only: following launches stop after the fused magnitude + gate pass (no frames)."""
         L.check(self._lib.adsb_debug_fused_pass_only(self._h, 1 if on else 0), "adsb_debug_fused_pass_only")
@@ -184,18 +181,6 @@ class AdsbDemod:
         n = C.c_size_t()
         L.check(self._lib.adsb_debug_tile_stamps(self._h, out.ctypes.data, max_tiles, C.byref(n)), "adsb_debug_tile_stamps")
         return out[:n.value].copy()
-
-    def stamps_waves(self):
-        out = np.zeros(16, dtype=np.uint64)
-        L.check(self._lib.adsb_debug_stamps_waves(self._h, out.ctypes.data), "adsb_debug_stamps_waves")
-        return out
-
-    def magnitude_table(self):
-        """The streaming kernel's 64 KB table, un-swizzled: entry (Q << 8) | I (as unsigned bytes)."""
-        raw = np.zeros(65536, dtype=np.uint8)
-        L.check(self._lib.adsb_debug_lut(self._h, raw.ctypes.data), "adsb_debug_lut")
-        r = np.arange(65536, dtype=np.uint32)
-        return raw[r ^ ((r >> 6) & 0x3FC)]
 
     # -- one received buffer (reference adsb.rs:95-116) -------------------------------------------
     def demod(self, iq, max_out=None):
@@ -297,6 +282,14 @@ class AdsbDemod:
         out = np.empty(n, dtype=np.uint16)
         L.check(self._lib.adsb_debug_magnitudes(self._h, iq.ctypes.data, n, out.ctypes.data),
                 "adsb_debug_magnitudes")
+        return out
+
+    def nsq_values(self, iq):
+        """I^2 + Q^2 + 72 per i8 sample through the scan kernel's packing code (0xFFFF: the two paths disagree)."""
+        iq = np.ascontiguousarray(iq, dtype=np.int8)
+        n = iq.shape[0]
+        out = np.empty(n, dtype=np.uint16)
+        L.check(self._lib.adsb_debug_nsq_values(self._h, iq.ctypes.data, n, out.ctypes.data), "adsb_debug_nsq_values")
         return out
 
     def synth_fill_device(self, cfg, channel, first_sample, n_samples, dev_ptr):

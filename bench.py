@@ -33,10 +33,12 @@ from air_rs_amd import sharding  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(iq_host_i8, target_seconds=15.0):
+def cpu_baseline(iq_host_i8, gpu_frames=None, target_seconds=15.0):
     """The CPU oracle (a plain-C port of the reference's thread 2; the Rust original cannot be built
     here) timed on this box's host cores, single thread like the reference, on a bounded prefix of
-    the same buffer."""
+    the same buffer.  The frame list of its last pass is also the checker of the GPU list of the same buffer
+    (`gpu_frames`: adsb_fetch of the last timed launch): offsets, bytes, status and repaired bit must be identical
+    over the offsets the oracle covered -> "parity_check" (full output compared)."""
     from tests.oracle_binding import Oracle
     orc = Oracle()
     probe = min(len(iq_host_i8), 1 << 22)
@@ -54,6 +56,17 @@ def cpu_baseline(iq_host_i8, target_seconds=15.0):
     out = {"value": round(passes * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
            "sample": f"first {n} samples of the same buffer x {passes} passes, {found} frames per pass, {dt:.1f} s, 1 thread",
            "msgs_per_s": round(passes * found / dt, 1)}
+    parity = None
+    if gpu_frames is not None:
+        try:
+            got = gpu_frames[gpu_frames["offset"] < np.uint64(n - 240)]   # the offsets the oracle's prefix covers
+            same = len(got) == len(frames) == found and bool((got == frames).all())
+            parity = {"ok": bool(same), "frames": int(len(frames)), "gpu_frames": int(len(got)), "samples": int(n),
+                      "what": "adsb_fetch of the last timed launch vs the CPU oracle over the same samples: offset, 14 bytes, status, fixed_bit"}
+            if not same and len(got) == len(frames):
+                parity["first_mismatch"] = int(np.nonzero(got != frames)[0][0])
+        except Exception as e:  # noqa: BLE001
+            parity = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     # Courtesy number: the same port on every host core this process may use, the buffer
     # time-sharded with the 240-sample overlap the multi-GPU path uses.  Not the reference's configuration
     # (its thread 2 is one thread); "value" above stays the single-thread rate.
@@ -75,7 +88,7 @@ def cpu_baseline(iq_host_i8, target_seconds=15.0):
                                 "cores": cores, "frames_per_pass": int(got), "passes": reps, "seconds": round(t_all, 1)}
     except Exception as e:  # the courtesy number must never cost the bench line
         out["all_cores"] = {"error": str(e)}
-    return out
+    return out, parity
 
 
 def main():
@@ -90,9 +103,9 @@ def main():
     ap.add_argument("--channels", type=int, default=1,
                     help="split the per-GPU buffer into this many independent channels handled by ONE launch "
                          "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
-    ap.add_argument("--kernel", choices=["default", "tiles", "stream"], default="default",
-                    help="i8 tile kernel: one workgroup per tile, or the streaming kernel (DESIGN.md section 4); "
-                         "default = the library's default (ADSB_KERNEL in the environment is honoured)")
+    ap.add_argument("--scan", choices=["default", "nsq", "root"], default="default",
+                    help="i8 scan kernel: nsq = the gate on I^2+Q^2 (the product's), root = floor(sqrt) per sample (the "
+                         "round-1/2 kernel, for A/B); default = the library's default (ADSB_SCAN in the environment is honoured)")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the multi-rank frame-list gather even with one rank (testing)")
     args = ap.parse_args()
@@ -104,8 +117,8 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
-    if args.kernel != "default":
-        os.environ["ADSB_KERNEL"] = args.kernel  # read by adsb_create
+    if args.scan != "default":
+        os.environ["ADSB_SCAN"] = args.scan  # read by adsb_create
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,6 +246,8 @@ def main():
             step()
         drain()
     m = measure(args.warmup, args.steps) if settle_s > 0 else cold
+    # untimed launches in front of the reported K steps: the cold run's W + K, the settle phase, the W of the reported run
+    warmup_total = args.warmup + ((args.warmup + args.steps + settle_launches) if settle_s > 0 else 0)
     dt, t_enq = m["dt"], m["t_enq"]
     demod_ms, decode_ms, order_ms, n_timed = m["demod_ms"], m["decode_ms"], m["order_ms"], m["n_timed"]
 
@@ -283,7 +298,7 @@ def main():
         # inside this process: the figure is the committed one for this exact workload and says so; null otherwise.
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc) and n == 1 << (29 if bps == 2 else 28) and nch == 1 and dem.kernel == "tiles":
+        if os.path.exists(pmc) and n == 1 << (29 if bps == 2 else 28) and nch == 1 and (bps == 4 or dem.scan == "nsq"):
             try:
                 pj = json.load(open(pmc))
                 key = "demod_tiles_hbm_bytes_per_launch" if bps == 2 else "demod_tiles_i16_hbm_bytes_per_launch"
@@ -295,7 +310,7 @@ def main():
         out = {
             "metric": f"IQ Msamples/s (decoded Mode-S msgs/s alongside), 2 MSPS {args.sample_type} stream",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": warmup_total, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.sample_type, "data": "synthetic",
             "config": {"workload": f"2 MSPS {args.sample_type} IQ, {bps * n / 2**30:g} GiB synthetic buffer per GPU, fused magnitude+preamble/DF17 gate+PPM+CRC-24",
                        "samples_per_gpu": n, "bytes_per_gpu": bps * n, "frames_per_step": int(frames_per_step),
@@ -306,9 +321,8 @@ def main():
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": ("adsbk::demod_stream_i8" if dem.kernel == "stream"
-                                    else f"adsbk::demod_tiles<{args.sample_type}>"), "kernel_ms": round(demod_ms, 4),
-                         "kernel_does": "scan kernel: reads every IQ byte once; fused magnitude + preamble/DF17 gate + PPM slice "
+                         "kernel": f"adsbk::demod_tiles<{args.sample_type}, {dem.scan}>", "kernel_ms": round(demod_ms, 4),
+                         "kernel_does": "scan kernel: reads every IQ byte once; fused (squared) magnitude + preamble/DF17 gate + PPM slice "
                                         "of the gate survivors (their CRC-24 / repair / ordering is finish_candidates)",
                          "finish_pass_ms": round(decode_ms, 4), "order_pass_ms": round(order_ms, 4), "launches_timed": n_timed,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -323,6 +337,9 @@ def main():
             "frac_of_read_ceiling": round(achieved / ceil_gbps, 4) if ceil_gbps > 0 else None}
         if gather_check is not None:
             out["gather_check"] = gather_check
+        out["warmup_requested"] = args.warmup
+        out["warmup_breakdown"] = {"cold_run_warmup": args.warmup, "cold_run_timed_steps": args.steps, "settle_launches": settle_launches,
+                                   "reported_run_warmup": args.warmup} if settle_s > 0 else {"reported_run_warmup": args.warmup}
         out["settle"] = {"seconds": settle_s, "launches": settle_launches,
                          "why": "untimed steps between the cold measurement and the reported one: the power controller needs ~0.1-0.2 s of "
                                 "load to converge (boost, overshoot, recovery); ADSB_BENCH_SETTLE_S=0 reports the cold run as value"}
@@ -335,7 +352,10 @@ def main():
 
         if world == 1 and not args.no_cpu_baseline and bps == 2 and nch == 1:
             sample = iq.cpu().numpy().reshape(-1, 2)  # the whole buffer: ~6-10 s on one host core
-            out["cpu_baseline"] = cpu_baseline(sample)
+            gpu_frames = dem.fetch()[0]               # the last timed launch's list (same buffer every step)
+            out["cpu_baseline"], parity = cpu_baseline(sample, gpu_frames)
+            if parity is not None:
+                out["parity_check"] = parity
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     dem.close()

@@ -269,9 +269,10 @@ int adsb_sample_type(const adsb_ctx *ctx);
  * (at most the 512 most recent launches) and clears the log.
  */
 int adsb_timing_enable(adsb_ctx *ctx, int on);
-/* The three kernels of a launch separately: the scan kernel (demod_tiles: magnitude + preamble/DF17 gate over every
- * sample -- the kernel that reads the IQ bytes), the decode kernel (decode_candidates: PPM slice + CRC-24 of the
- * gate survivors) and the ordering pass (gather_tiles).  adsb_timing_read reports the first and the last. */
+/* The three kernels of a launch separately: the scan kernel (demod_tiles: squared magnitude + preamble/DF17 gate
+ * over every sample + PPM slice of the gate's survivors -- the kernel that reads the IQ bytes), the finishing kernel
+ * (finish_candidates: CRC-24, single-bit repair and ordering inside a tile, one lane per survivor; reported as
+ * decode_ms) and the ordering pass (gather_tiles).  adsb_timing_read reports the first and the last. */
 int adsb_timing_read3(adsb_ctx *ctx, double *scan_ms_mean, double *decode_ms_mean, double *order_ms_mean,
                       uint32_t *n_launches);
 int adsb_timing_read(adsb_ctx *ctx, double *demod_ms_mean, double *order_ms_mean,
@@ -286,31 +287,26 @@ int adsb_debug_magnitudes(adsb_ctx *ctx, const void *iq_host, size_t n_samples,
 /* How v_cvt_pk_u8_f32 was found to round on this device: 0 truncates, 1 truncates under
  * MODE.fp_round = toward-zero, 2 rounds to nearest (kernel subtracts 0.5 first). */
 int adsb_debug_mag_mode(adsb_ctx *ctx);
-/* Measurement only: with on != 0 the following launches run the scan kernel (the fused magnitude +
- * preamble/DF17 pass) and the ordering pass but not the decode kernel -- gate survivors are listed but not sliced
- * or CRC-checked, so NO frames come out.  on = 0 restores the full path. */
+/* v = I^2 + Q^2 + 72 of n host i8 samples through the packing code of the scan kernel's phase 1 (the gate and the
+ * slicer of the i8 path work on these; utils.rs:46-52's root is only taken where a comparison needs it).  0xFFFF marks
+ * a sample whose two packing paths disagree.  ADSB_E_STATE for a CS16 context. */
+int adsb_debug_nsq_values(adsb_ctx *ctx, const void *iq_host, size_t n_samples, uint16_t *vals_host);
+/* Measurement only: with on != 0 the following launches run the scan kernel (squared magnitude + preamble/DF17
+ * gate + slice of the survivors) and the ordering pass but not the finishing kernel -- no survivor is CRC-checked, so
+ * NO frames come out.  on = 0 restores the full path. */
 int adsb_debug_fused_pass_only(adsb_ctx *ctx, int on);
-/* Which kernel the context launches: 0 = demod_tiles, one workgroup per tile -- the only kernel of the product
- * build, for i8 and i16 alike.  1 = the experimental streaming kernel (one persistent workgroup per CU,
- * magnitudes by table lookup), which exists only in libraries built with -DADSB_WITH_STREAM_KERNEL=1
- * (tools/experimental/) and is then selected by ADSB_KERNEL=stream in the environment at adsb_create; in the
- * product build that setting makes adsb_create fail with ADSB_E_ARG. */
-int adsb_debug_kernel(adsb_ctx *ctx);
-/* Experimental streaming kernel only: its 64 KB magnitude table as it sits on the device: entry
- * r ^ ((r >> 6) & 0x3FC) holds floor(sqrt(I^2+Q^2)) of the raw sample r = (Q << 8) | I (utils.rs:46-52).
- * ADSB_E_STATE if the context does not use the streaming kernel (always, in the product build). */
-int adsb_debug_lut(adsb_ctx *ctx, uint8_t *table_host65536);
-/* Diagnostic builds of the streaming kernel (-DADSB_STAMPS=1) only: per-segment shader-cycle sums of
- * workgroup 0 over the last launch (zeros in a normal build). */
-int adsb_debug_stamps(adsb_ctx *ctx, uint64_t out16[16]);
+/* Which scan kernel an i8 context launches: 0 = the gate on n = I^2+Q^2 (default), 1 = the round-1/2 kernel with
+ * floor(sqrt) per sample, selected by ADSB_SCAN=root in the environment at adsb_create (A/B measurements; same
+ * results).  Always 1 for CS16 (one kernel). */
+int adsb_debug_scan(adsb_ctx *ctx);
+/* Test knob: with on != 0 the shared slot pool of the following launches hands out nothing, so every tile with
+ * more gate survivors than its own 32 slots loses them: the launch's list comes out with ADSB_FLAG_INCOMPLETE (for
+ * device-side consumers) and the host entry points take their re-run path -- deterministically. */
+int adsb_debug_pool_limit(adsb_ctx *ctx, int on);
 /* Diagnostic builds of demod_tiles (-DADSB_TILE_STAMPS=1) only: 16 uint32 per tile of the last launch (waves 0
  * and 3 of the tile's workgroup, 8 each: shader cycles in prologue, phase 1, barrier, phase 2, barrier, phase 3,
  * wait for the loads; s_memrealtime at start).  ADSB_E_STATE in a normal build. */
 int adsb_debug_tile_stamps(adsb_ctx *ctx, uint32_t *out16_per_tile, size_t max_tiles, size_t *n_tiles);
-/* Same builds: cycles each of workgroup 0's 16 waves spent between leaving one round barrier and reaching
- * the next, summed over the last launch (which wave a round waits for). */
-int adsb_debug_stamps_waves(adsb_ctx *ctx, uint64_t out16[16]);
-
 /* ---- deterministic synthetic IQ source --------------------------------------- */
 typedef struct adsb_synth_cfg {
     uint64_t seed;

@@ -10,24 +10,18 @@ import air_rs_amd as A
 pytestmark = pytest.mark.gpu
 
 
-def _kernel_kinds():
-    # The product build has one kernel (demod_tiles).  A library built with the experimental streaming kernel
-    # (tools/build_variant.sh stream -DADSB_WITH_STREAM_KERNEL=1 -Itools/experimental, used via ADSB_HIP_LIB)
-    # runs the whole module a second time with ADSB_KERNEL=stream when ADSB_TEST_STREAM_KERNEL=1 is set.
-    return ["tiles", "stream"] if os.environ.get("ADSB_TEST_STREAM_KERNEL") == "1" else ["tiles"]
-
-
-@pytest.fixture(scope="module", params=_kernel_kinds(), autouse=True)
-def kernel_kind(request):
-    """Every test of this module runs once per i8 kernel under test: demod_tiles (the default and only kernel
-    of the product build), and the experimental streaming kernel when asked for (see _kernel_kinds)."""
-    old = os.environ.get("ADSB_KERNEL")
-    os.environ["ADSB_KERNEL"] = request.param
+@pytest.fixture(scope="module", params=["nsq", "root"], autouse=True)
+def scan_kind(request):
+    """Every i8 test of this module runs once per i8 scan kernel: "nsq" (the product's: the gate on I^2+Q^2) and
+    "root" (the round-1/2 kernel with floor(sqrt) per sample, kept for A/B measurements -- it must stay bit-exact
+    too).  ADSB_SCAN is read by adsb_create."""
+    old = os.environ.get("ADSB_SCAN")
+    os.environ["ADSB_SCAN"] = request.param
     yield request.param
     if old is None:
-        os.environ.pop("ADSB_KERNEL", None)
+        os.environ.pop("ADSB_SCAN", None)
     else:
-        os.environ["ADSB_KERNEL"] = old
+        os.environ["ADSB_SCAN"] = old
 
 
 def _eq(got, want):
@@ -48,9 +42,9 @@ def _check(dem, oracle, iq, max_out=None):
 
 
 @pytest.fixture(scope="module")
-def dem8(gpu, kernel_kind):
+def dem8(gpu, scan_kind):
     with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 18) as d:
-        assert d.kernel == kernel_kind
+        assert d.scan == scan_kind
         yield d
 
 
@@ -69,15 +63,14 @@ def test_magnitude_i8_exhaustive(dem8, oracle):
     assert (got == want).all(), (dem8.mag_mode, np.nonzero(got != want)[0][:10])
 
 
-def test_magnitude_table_exhaustive(dem8, oracle, kernel_kind):
-    # the streaming kernel's 64 KB table: floor(sqrt(I^2+Q^2)) for every raw sample (Q << 8) | I
-    if kernel_kind != "stream":
-        pytest.skip("the tile kernel computes magnitudes arithmetically (test above)")
-    table = dem8.magnitude_table()
-    r = np.arange(65536, dtype=np.uint32)
-    iq = np.stack([(r & 0xFF).astype(np.uint8).view(np.int8), (r >> 8).astype(np.uint8).view(np.int8)], axis=1)
-    want = oracle.get_magnitude(iq.astype(np.int16))
-    assert (table == want).all(), np.nonzero(table != want)[0][:10]
+def test_nsq_values_exhaustive(dem8):
+    # every (I, Q) an i8 stream can carry through the nsq kernel's packing code (dot4 for the low half, perm + dot2
+    # for the high half): I^2 + Q^2 + 72 in both halves
+    i, q = np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij")
+    iq = np.stack([i.ravel(), q.ravel()], axis=1).astype(np.int8)
+    got = dem8.nsq_values(iq).astype(np.int64)
+    want = (iq.astype(np.int64) ** 2).sum(axis=1) + 72
+    assert (got == want).all(), np.nonzero(got != want)[0][:10]
 
 
 def test_magnitude_i16(dem16, oracle):
@@ -96,8 +89,8 @@ def test_magnitude_i16(dem16, oracle):
     assert (dem16.magnitudes(iq) == oracle.get_magnitude(iq)).all()
 
 
-@pytest.mark.parametrize("n", [240, 241, 255, 271, 272, 1000, 20000, 32768 + 239, 32768 + 240, 32768 + 241,
-                               65536 + 240, 100003])
+@pytest.mark.parametrize("n", [240, 241, 255, 271, 272, 1000, 8192 + 239, 8192 + 241, 16384 + 239, 16384 + 240,
+                               16384 + 241, 20000, 32768 + 239, 32768 + 240, 32768 + 241, 65536 + 240, 100003])
 def test_synthetic_sizes_i8(dem8, oracle, n):
     cfg = A.synth_default(seed=100 + n, slot_len=600)
     iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, n)
@@ -275,12 +268,14 @@ def test_64_channel_batch(gpu, oracle):
         assert total > 64 * 30
 
 
-def test_large_streaming_buffer_sampled(gpu, oracle):
+def test_large_streaming_buffer_sampled(gpu, oracle, scan_kind):
     # BASELINE config 3 regime (buffer much larger than the caches, > 4 GiB of offsets arithmetic):
     # 5 GiB of i8 IQ generated on the device, whole-buffer demod, parity on sampled sub-ranges via
     # the size-independent property that any sub-range demodulated alone gives the same frames
     # (every offset is independent).
     import torch
+    if scan_kind != "nsq":
+        pytest.skip("the 5 GiB buffer runs once, through the product's scan kernel")
     n = 5 * (1 << 29)  # 2.68 G samples = 5 GiB: byte offsets cross 2^32
     cfg = A.synth_default(seed=333)
     t = torch.empty(n * 2, dtype=torch.int8, device="cuda")
@@ -393,26 +388,120 @@ def test_on_device_field_decode(gpu, oracle):
             assert g["callsign"].decode() == k["callsign"]
 
 
-@pytest.mark.parametrize("grid", [1, 3, 7])
-def test_stream_kernel_many_rounds_per_workgroup(gpu, oracle, kernel_kind, grid):
-    """The streaming kernel's persistent workgroups walk tiles b, b + G, b + 2G, ...: with the default grid
-    (one workgroup per CU) the buffers of this suite give every workgroup a single tile, so pin the grid to a
-    few workgroups and make each run many rounds (double-buffered magnitudes, parity-buffered lists, deferred
-    records) -- sparse rounds, dense rounds (constant stretch: a frame per offset) and the ragged last tile."""
-    if kernel_kind != "stream":
-        pytest.skip("streaming kernel only")
-    os.environ["ADSB_STREAM_GRID"] = str(grid)
-    try:
-        cfg = A.synth_default(seed=4000 + grid, slot_len=700)
-        n = 32768 * 21 + 12345
-        iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, n)
-        iq[32768 * 5 + 100:32768 * 5 + 2100] = 17        # constant stretch: > 64 survivors in tile 5 (dense round)
-        iq[32768 * 6 - 50:32768 * 6 + 400] = -3          # ... and one straddling a tile edge
-        with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=n, max_out=1 << 16) as d:
-            assert d.kernel == "stream"
-            fr = _check(d, oracle, iq)
-            assert len(fr) > 2500
-            fr2 = _check(d, oracle, iq[: 32768 * 9 + 241])   # same context, shorter buffer
-            assert 0 < len(fr2) < len(fr)
-    finally:
-        os.environ.pop("ADSB_STREAM_GRID", None)
+# ---- the nsq gate: ties after truncation, decided on n = I^2 + Q^2 ------------------------------------------------
+def _gate_buf(hi_iq, lo_iq, df_hi=None, df_lo=None, n=241):
+    """241 samples: preamble highs / lows as given (I, Q) pairs, DF17 highs / lows (default: all equal), then zeros."""
+    buf = np.zeros((n, 2), dtype=np.int8)
+    buf[[0, 2, 7, 9]] = hi_iq
+    buf[[1, 3, 4, 5, 6, 8, 10, 11, 12, 13, 14, 15]] = lo_iq
+    if df_hi is not None:
+        buf[[16 + k for k in (0, 3, 5, 7, 8)]] = df_hi
+        buf[[16 + k for k in (1, 2, 4, 6, 9)]] = df_lo
+    return buf
+
+
+def test_gate_ties_after_truncation(dem8, oracle):
+    """The reference compares floor(sqrt(I^2+Q^2)) (utils.rs:46-52, demod.rs:27-36, 48-54): a "high" with a SMALLER
+    n than a "low" still passes when their truncated roots are equal.  Sums of two squares around every root
+    boundary an i8 sample can reach: (high n, low n) with high < low inside one root class (passes), across a class
+    boundary (fails), and equal / reversed; in the preamble group and in the DF17 group; including the nine values
+    with |I|, |Q| >= 125 that are no ordered f16 patterns (the tile then takes the integer gate)."""
+    # representable n -> one (I, Q)
+    rep = {}
+    for i in range(0, 129):
+        for q in range(i, 129):
+            rep.setdefault(i * i + q * q, (-i if i == 128 else i, -q if q == 128 else q))
+    ns = np.array(sorted(rep))
+    roots = np.floor(np.sqrt(ns)).astype(int)
+    cases = []
+    rng = np.random.default_rng(3)
+    for r in list(range(0, 182)):
+        cls = ns[roots == r]
+        if len(cls) >= 2:
+            cases.append((int(cls[0]), int(cls[-1]), True))    # smallest high, largest low of one class: tie, passes
+            cases.append((int(cls[-1]), int(cls[0]), True))
+        nxt = ns[roots == r + 1]
+        if len(cls) and len(nxt):
+            cases.append((int(cls[-1]), int(nxt[0]), False))   # adjacent classes: high root < low root
+            cases.append((int(nxt[0]), int(cls[-1]), True))
+    cases = [cases[k] for k in rng.permutation(len(cases))]
+    n_pass = 0
+    for hi_n, lo_n, expect in cases:
+        for where in ("preamble", "df17"):
+            if where == "preamble":
+                buf = _gate_buf(rep[hi_n], rep[lo_n])
+                buf[16:] = 0
+                ok_rest = True  # DF17 region all zero: ties pass
+            else:
+                buf = _gate_buf((90, 0), (10, 0), rep[hi_n], rep[lo_n])
+                ok_rest = True
+            frames, flags = dem8.demod(buf)
+            rc, want, n = oracle.process_buffer(buf)
+            assert rc == 0 and flags == 0
+            _eq(frames, want)
+            # the gate verdict itself (a passing gate need not yield a frame: the CRC decides)
+            m = oracle.get_magnitude(buf.astype(np.int16))
+            assert (oracle.check_for_adsb_packet(m[:32]) is not None) == (expect and ok_rest), (hi_n, lo_n, where)
+            n_pass += len(want)
+    assert n_pass > 50
+
+
+def test_gate_band_random_windows(dem8, oracle):
+    """Dense random windows drawn so that highs and lows sit within a few units of each other at many amplitude
+    levels (the band the nsq gate has to resolve with roots), and pairs of the slicer within one root class: every
+    buffer against the oracle."""
+    rng = np.random.default_rng(99)
+    for level in (0, 1, 2, 3, 5, 8, 13, 20, 35, 60, 90, 110, 124, 126):
+        spread = max(1, level // 6)
+        iq = rng.integers(max(-128, level - spread - 1), min(127, level + spread + 1) + 1, size=(60_000, 2)).astype(np.int8)
+        sign = rng.choice(np.array([-1, 1], dtype=np.int8), size=iq.shape)
+        iq = (iq.astype(np.int16) * sign).clip(-128, 127).astype(np.int8)
+        frames, flags = dem8.demod(iq)
+        rc, want, n = oracle.process_buffer(iq)
+        assert rc == 0 and flags == 0
+        _eq(frames, want)
+
+
+def test_full_scale_samples_in_some_tiles(dem8, oracle):
+    """A realistic stream with |I|, |Q| >= 125 samples (n + 72 >= 0x7C00: not an ordered f16 pattern) dropped into
+    tiles 1, 4 and 7 only: those tiles run the integer gate, the others the three-input f16 gate, in one launch."""
+    rng = np.random.default_rng(21)
+    cfg = A.synth_default(seed=271, slot_len=700)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 300_000)
+    frames, flags = dem8.demod(iq)
+    rc, want, n_clean = oracle.process_buffer(iq)
+    _eq(frames, want)
+    for t in (1, 4, 7):
+        pos = rng.integers(t * 16384, (t + 1) * 16384, size=40)
+        iq[pos] = rng.choice(np.array([-128, -127, -126, -125, 125, 126, 127], dtype=np.int8), size=(40, 2))
+    frames, flags = dem8.demod(iq)
+    rc, want, n = oracle.process_buffer(iq)
+    assert rc == 0 and flags == 0 and n > 0.9 * n_clean
+    _eq(frames, want)
+    # and a whole buffer of nothing but such samples (every tile in integer mode; many ties)
+    iq = rng.choice(np.array([-128, -127, -126, -125, 125, 126, 127], dtype=np.int8), size=(120_000, 2))
+    frames, flags = dem8.demod(iq)
+    rc, want, n = oracle.process_buffer(iq)
+    _eq(frames, want)
+
+
+def test_zero_tile_launch_clears_flags(gpu):
+    """a 240-sample launch (zero offsets, adsb.rs:98 iterates 0..0) runs no scan kernel; its result set's
+    flag words must not keep TRUNCATED from the launch two before it -- in the ctx header and in a caller-owned blob."""
+    import torch
+    with A.AdsbDemod(max_samples=5000, max_out=100, host_staging=False) as d:
+        zeros = torch.zeros(5000 * 2, dtype=torch.int8, device="cuda")
+        blob = torch.full((32 + 100 * 24,), 0xEE, dtype=torch.uint8, device="cuda")
+        for use_blob in (False, True):
+            d.set_result_target(blob.data_ptr(), blob.numel()) if use_blob else d.set_result_target(None, 0)
+            d.demod_device_async(zeros.data_ptr(), 5000)          # 4760 all-zero frames: truncated to 100
+            assert d.fetch_counts()[2] & A.ADSB_FLAG_TRUNCATED
+            d.demod_device_async(zeros.data_ptr(), 5000)          # the other result set
+            d.demod_device_async(zeros.data_ptr(), 240)           # same set as the first launch, no tiles
+            n_out, total, flags = d.fetch_counts()
+            assert (n_out, total, flags) == (0, 0, 0)
+            if use_blob:
+                torch.cuda.synchronize()
+                hdr = blob[:32].cpu().numpy().view(np.uint64)
+                assert tuple(hdr[:3]) == (0, 0, 0)
+        d.set_result_target(None, 0)

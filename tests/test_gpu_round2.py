@@ -86,36 +86,32 @@ def test_shard_plan_through_hip_equals_single_buffer(gpu, oracle, st, total, wor
 
 # ---- the zero-copy path must not hand out a list with holes silently --------------------------------
 def test_zero_copy_consumer_sees_incomplete_flag_and_repair(gpu, oracle):
-    """All-zero input: every offset is a valid all-zero frame and every tile wants 32768 slots from a
-    pool of max_out + 32768.  With 128 tiles and max_out = 1000 only one tile gets its slots, and it is the first
-    tile (the only one whose frames are wanted) only if it happens to ask first: practically always the wanted
-    frames are missing after the first pass.  A device-side consumer (adsb_set_result_target blob) must then see
-    ADSB_FLAG_INCOMPLETE in the blob header; adsb_fetch_counts() re-plans, completes the blob IN PLACE and clears
-    the flag.  (Which tile wins is a race: the launch is repeated a few times and must show the flag at least once;
-    whatever the first pass did, the blob must be right after adsb_fetch_counts.)"""
+    """All-zero input: every offset is a valid all-zero frame, so every tile has 16384 survivors and asks
+    the shared pool for slots.  With the pool switched off (adsb_debug_pool_limit: deterministic, no race for the
+    pool) every tile loses its slots, the wanted frames are missing after the first pass, and a device-side consumer
+    (adsb_set_result_target blob) must see ADSB_FLAG_INCOMPLETE in the blob header; adsb_fetch_counts() re-plans
+    (the knob is off again by then), completes the blob IN PLACE and clears the flag."""
     import torch
-    n, cap = 1 << 22, 1000
+    n, cap = 1 << 20, 1000
     iq = np.zeros((n, 2), dtype=np.int8)
     rc, want, cnt = oracle.process_buffer(iq[:4096], max_out=cap)   # the first `cap` offsets, all-zero frames
     assert len(want) == cap
-    seen_incomplete = 0
     with A.AdsbDemod(max_samples=n, max_out=cap, host_staging=False) as d:
         t = torch.from_numpy(iq).cuda()
         blob = torch.full((sharding.payload_bytes(cap),), 0xEE, dtype=torch.uint8, device="cuda")
         side = torch.cuda.Stream()
-        for attempt in range(4):
+        for attempt in range(2):
             blob.fill_(0xEE)
             torch.cuda.synchronize()
             d.set_result_target(blob.data_ptr(), blob.numel())
+            d.pool_limit(True)
             d.demod_device_async(t.data_ptr(), n)
+            d.pool_limit(False)
             d.stream_wait_results(side.cuda_stream)
             side.synchronize()
             n_out, total, flags, frames = sharding.parse_payload(blob.cpu().numpy())
             assert n_out == cap and total == n - 240 and flags & A.ADSB_FLAG_TRUNCATED
-            if flags & A.ADSB_FLAG_INCOMPLETE:
-                seen_incomplete += 1
-            else:                                       # tile 0 won the pool: the list is whole already
-                _eq(frames.copy(), want)
+            assert flags & A.ADSB_FLAG_INCOMPLETE, "every tile lost its slots: the blob must say so"
             n2, total2, flags2 = d.fetch_counts()       # the host entry point re-plans what is missing ...
             assert (n2, total2) == (cap, n - 240)
             assert not (flags2 & A.ADSB_FLAG_INCOMPLETE) and flags2 & A.ADSB_FLAG_TRUNCATED
@@ -123,25 +119,29 @@ def test_zero_copy_consumer_sees_incomplete_flag_and_repair(gpu, oracle):
             assert not (flags & A.ADSB_FLAG_INCOMPLETE) and flags & A.ADSB_FLAG_TRUNCATED
             _eq(frames.copy(), want)                    # ... and the blob is whole, in place
         d.set_result_target(None, 0)
-    assert seen_incomplete >= 1, "the slot-pool overflow never showed in the blob header"
+        # the knob left no trace: a plain launch gives a whole list straight away
+        d.demod_device_async(t.data_ptr(), n)
+        frames, counts, total, flags = d.fetch()
+        assert not (flags & A.ADSB_FLAG_INCOMPLETE)
+        _eq(frames, want)
 
 
-def test_streaming_kernel_is_not_in_the_product_build(gpu):
-    if os.environ.get("ADSB_TEST_STREAM_KERNEL") == "1":
-        pytest.skip("experimental library under test")
-    old = os.environ.get("ADSB_KERNEL")
-    os.environ["ADSB_KERNEL"] = "stream"
-    try:
-        with pytest.raises(A.AdsbError) as e:
-            A.AdsbDemod(max_samples=4096, max_out=16)
-        assert e.value.code == A.ADSB_E_ARG
-    finally:
-        if old is None:
-            os.environ.pop("ADSB_KERNEL", None)
-        else:
-            os.environ["ADSB_KERNEL"] = old
+def test_scan_kernel_selection(gpu, monkeypatch):
+    """ADSB_SCAN at adsb_create: default and "nsq" = the product's i8 scan kernel, "root" = the A/B kernel, anything
+    else is refused; CS16 has one kernel."""
+    monkeypatch.delenv("ADSB_SCAN", raising=False)
     with A.AdsbDemod(max_samples=4096, max_out=16) as d:
-        assert d.kernel == "tiles"
+        assert d.scan == "nsq"
+    monkeypatch.setenv("ADSB_SCAN", "root")
+    with A.AdsbDemod(max_samples=4096, max_out=16) as d:
+        assert d.scan == "root"
+    monkeypatch.setenv("ADSB_SCAN", "stream")
+    with pytest.raises(A.AdsbError) as e:
+        A.AdsbDemod(max_samples=4096, max_out=16)
+    assert e.value.code == A.ADSB_E_ARG
+    monkeypatch.setenv("ADSB_SCAN", "nsq")
+    with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=4096, max_out=16) as d:
+        assert d.scan == "root"
 
 
 def test_fetch_counts_array_is_sized_for_the_launch(gpu, oracle):
