@@ -42,6 +42,16 @@ class AdsbFeedCfg(C.Structure):
     _fields_ = [("max_chunk", C.c_size_t), ("carry", C.c_uint32), ("ring_slots", C.c_uint32)]
 
 
+class AdsbGroupCfg(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("sample_type", C.c_int32), ("n_members", C.c_uint32), ("root", C.c_uint32),
+                ("devices", C.POINTER(C.c_int32)), ("max_samples", C.c_uint64), ("max_out", C.c_uint64),
+                ("host_staging", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class AdsbGroupShard(C.Structure):
+    _fields_ = [("first_sample", C.c_uint64), ("n_samples", C.c_uint64), ("n_offsets", C.c_uint64)]
+
+
 class AdsbSynthCfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("slot_len", C.c_uint32), ("frame_pct", C.c_uint32),
                 ("pct_flip_data", C.c_uint32), ("pct_flip_crc", C.c_uint32),
@@ -120,7 +130,19 @@ PROTOTYPES = {
     "adsb_feed_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_feed_pop": (C.c_int, [C.c_void_p, _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint32), _P(C.c_uint64)]),
     "adsb_feed_in_flight": (C.c_int, [C.c_void_p]),
+    "adsb_feed_ready": (C.c_int, [C.c_void_p]),
     "adsb_feed_close": (None, [C.c_void_p]),
+    "adsb_group_create": (C.c_int, [_P(AdsbGroupCfg), _P(C.c_void_p)]),
+    "adsb_group_destroy": (None, [C.c_void_p]),
+    "adsb_group_size": (C.c_uint32, [C.c_void_p]),
+    "adsb_group_member": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "adsb_group_plan": (C.c_int, [C.c_uint64, C.c_uint32, _P(AdsbGroupShard)]),
+    "adsb_group_demod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _P(AdsbFrame), C.c_size_t, _P(C.c_size_t),
+                                   _P(C.c_uint32)]),
+    "adsb_group_demod_host_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_group_demod_device_async": (C.c_int, [C.c_void_p, _P(C.c_void_p), C.c_size_t]),
+    "adsb_group_fetch": (C.c_int, [C.c_void_p, _P(AdsbFrame), C.c_size_t, _P(C.c_size_t), _P(C.c_uint64), _P(C.c_uint32)]),
+    "adsb_group_result_device": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p)]),
     "adsb_set_result_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_set_stream_base": (C.c_int, [C.c_void_p, C.c_uint64]),
     "adsb_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -79,7 +79,7 @@ struct adsb_ctx {
     uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
     unsigned long long *stamps = nullptr; // cycle counters of diagnostic builds (64 bytes per tile with -DADSB_TILE_STAMPS=1)
     size_t stamps_bytes = 0;
-    int scan = adsbk::kScanNsq;     // which i8 scan kernel (ADSB_SCAN=root selects the A/B kernel at adsb_create)
+    int scan = adsbk::kScanRoot;    // which i8 scan kernel (ADSB_SCAN=nsq selects the A/B kernel at adsb_create)
     bool pool_off = false;          // adsb_debug_pool_limit: the shared slot pool hands out nothing (test knob)
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
@@ -182,11 +182,13 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     if (!c) return ADSB_E_NOMEM;
     c->cfg = *cfg;
     c->bps = cfg->sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
-    // i8 has two scan kernels: the product's (the gate on n = I^2+Q^2, no root per sample) and the round-1/2 one
-    // (floor(sqrt) per sample), kept for A/B measurements: ADSB_SCAN=root in the environment at adsb_create.
+    // i8 has two scan kernels: the product's (floor(sqrt) per sample, u8 magnitudes in LDS: eight workgroups per
+    // CU) and the round-3 A/B kernel whose gate works on n = I^2+Q^2 (no root per sample, but 2 bytes of LDS per
+    // sample: four workgroups per CU; 10 % fewer VALU slots, 12 % slower -- DESIGN.md section 5.3): ADSB_SCAN=nsq in
+    // the environment at adsb_create selects it.
     if (const char *sc = getenv("ADSB_SCAN")) {
-        if (strcmp(sc, "root") == 0) c->scan = adsbk::kScanRoot;
-        else if (strcmp(sc, "nsq") == 0 || sc[0] == 0) c->scan = adsbk::kScanNsq;
+        if (strcmp(sc, "nsq") == 0) c->scan = adsbk::kScanNsq;
+        else if (strcmp(sc, "root") == 0 || sc[0] == 0) c->scan = adsbk::kScanRoot;
         else { delete c; return ADSB_E_ARG; }
     }
     uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type) * cfg->max_channels;
@@ -319,7 +321,7 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.hdr_pub = (count_groups && c->ext_blob) ? static_cast<uint64_t *>(c->ext_blob) : nullptr;
     a.grp1 = grp1_of(c, grp_set);
     a.grp2 = grp2_of(c, grp_set);
-    a.pool_off = c->pool_off ? 1u : 0u;
+    a.pool_off = (c->pool_off && count_groups) ? 1u : 0u; // (first passes only: the re-run of lost tiles needs the pool)
     a.stamps = c->stamps;
     return a;
 }
@@ -975,6 +977,21 @@ extern "C" int adsb_feed_open(adsb_ctx *c, const adsb_feed_cfg *cfg, adsb_feed *
 }
 
 extern "C" int adsb_feed_in_flight(const adsb_feed *f) { return f ? (int)(f->pushed - f->popped) : ADSB_E_ARG; }
+
+// 1: adsb_feed_pop() would not wait for the GPU (the oldest buffer's kernels have finished, or it launched none);
+// 0: it would; ADSB_E_STATE: nothing in flight.
+extern "C" int adsb_feed_ready(adsb_feed *f)
+{
+    if (!f) return ADSB_E_ARG;
+    if (f->popped == f->pushed) return ADSB_E_STATE;
+    const uint32_t s = (uint32_t)(f->popped & 1u);
+    if (!f->q[s].launched) return 1;
+    HIPCHK(hipSetDevice(f->c->cfg.device));
+    const hipError_t e = hipEventQuery(f->kern_done[s]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return (int)e;
+}
 
 static int feed_ring_slot(adsb_feed *f, uint32_t *slot)
 {

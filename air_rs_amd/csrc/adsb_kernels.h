@@ -37,9 +37,10 @@ constexpr int tile_offsets(int sample_type)
     return sample_type == ADSB_SAMPLE_I8 ? kTile : 2 * kThreads * kRunI16;
 }
 constexpr int kTileMax = kTile > 2 * kThreads * kRunI16 ? kTile : 2 * kThreads * kRunI16;
-// Which i8 scan kernel a context launches (adsb_create reads ADSB_SCAN from the environment; default nsq):
-//   kScanNsq : the gate runs on n = I^2+Q^2 (no root per sample; exact: DESIGN.md section 4.1)
-//   kScanRoot: the round-1/2 kernel, floor(sqrt(n)) per sample (v_sqrt_f32), kept for A/B measurements
+// Which i8 scan kernel a context launches (adsb_create reads ADSB_SCAN from the environment; default root):
+//   kScanRoot: floor(sqrt(n)) per sample (v_sqrt_f32), u8 magnitudes in LDS -- the product's kernel
+//   kScanNsq : the gate runs on n = I^2+Q^2 (no root per sample; exact: DESIGN.md section 4.1b), 2 bytes of LDS per
+//              sample; the round-3 A/B kernel (fewer VALU slots, half the resident workgroups: slower)
 constexpr int kScanNsq = 0, kScanRoot = 1;
 constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
 constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path

@@ -273,9 +273,14 @@ template <> struct MagT<ADSB_SAMPLE_I16> { typedef uint16_t type; };
 constexpr int kNsqBias = 72;                 // 9 * 8: (v >> 3) = (n >> 3) + 9 exactly
 constexpr int kNsqHalf = kTile / 2;          // 8192
 constexpr int kNsqLog = kNsqHalf + kHalo;    // logical dwords
-constexpr int nsq_phys(int q) { return q + 4 * (q >> 6); }
-constexpr int kNsqPhys = nsq_phys(kNsqLog);  // 8976 dwords = 35904 bytes
-static_assert(kNsqHalf % 64 == 0 && kHalo % 64 == 0 && kRun == 32, "nsq image: pads every 64 dwords, runs of 32");
+#ifndef ADSB_NSQ_PAD_SHIFT
+#define ADSB_NSQ_PAD_SHIFT 6 // four pad dwords per 2^6 logical dwords (5: per 32 -- also conflict-free for the stores, 6 % more LDS)
+#endif
+constexpr int kNsqPadShift = ADSB_NSQ_PAD_SHIFT;
+__host__ __device__ constexpr uint32_t nsq_phys(uint32_t q) { return q + 4u * (q >> kNsqPadShift); }
+constexpr int kNsqPhys = (int)nsq_phys(kNsqLog);  // 8976 dwords = 35904 bytes
+static_assert(kNsqHalf % 64 == 0 && kHalo % 64 == 0 && kRun == 32 && (kNsqPadShift == 5 || kNsqPadShift == 6),
+              "nsq image: pads every 32 or 64 dwords, runs of 32");
 
 template <int ST, int SCAN = kScanRoot> struct Lds {
     typedef typename MagT<ST>::type mag_t;
@@ -407,9 +412,10 @@ __device__ __forceinline__ uint32_t nsq_slice_byte(const uint32_t *img, const ui
     const uint32_t base = off - half * (uint32_t)kNsqHalf + 16u; // logical dword of the first data sample
     const uint32_t e = base & 15u, par = e & 1u, sh = e >> 1;
     const uint32_t v = (base >> 4) + l;                            // this lane's 16-sample chunk
-    const uint32_t a1 = 16u * v + 4u * (v >> 2) + par;            // physical dword of its first sample
-    // its last sample sits behind a pad when the chunk ends a 64-block and was moved up by one
-    const uint32_t a2 = a1 + 15u + (((v & 3u) == 3u ? 4u : 0u) & (0u - par));
+    const uint32_t a1 = nsq_phys(16u * v) + par;                  // physical dword of its first sample
+    // its last sample sits behind a pad when the chunk ends a padded block and was moved up by one
+    constexpr uint32_t kChunksPerBlock = (1u << kNsqPadShift) / 16u;
+    const uint32_t a2 = a1 + 15u + (((v & (kChunksPerBlock - 1u)) == kChunksPerBlock - 1u ? 4u : 0u) & (0u - par));
     uint32_t d[16];
 #pragma unroll
     for (int j = 0; j < 15; ++j) d[j] = img[a1 + j];
@@ -793,6 +799,8 @@ constexpr int kNsqFull = kNsqLog / (kThreads * 8);  // sweeps every lane takes p
 constexpr int kNsqTail = kNsqLog % (kThreads * 8);  // logical dwords of the last, partial sweep (the halo: 256)
 static_assert(kNsqIters - kNsqFull <= 1 && kNsqTail % 8 == 0, "at most one partial sweep of whole lanes");
 
+// sweeps [IT0, IT1) of a tile's loads
+template <int IT0 = 0, int IT1 = kNsqIters>
 __device__ __forceinline__ void nsq_issue_loads(const DemodArgs &p, const TilePos &tp, uint32_t tid,
                                                 u32x4 (&ra)[kNsqIters], u32x4 (&rb)[kNsqIters])
 {
@@ -800,11 +808,12 @@ __device__ __forceinline__ void nsq_issue_loads(const DemodArgs &p, const TilePo
     // (the sweep's constant goes into the SGPR offset, which the descriptor's bounds check covers:
     // tools/ubench/soffset_probe.hip; reads past the channel end return zeros)
 #pragma unroll
-    for (int it = 0; it < kNsqFull; ++it) {
+    for (int it = IT0; it < (IT1 < kNsqFull ? IT1 : kNsqFull); ++it) {
         ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16), ADSB_LOAD_AUX);
         rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16) + 2 * kNsqHalf, ADSB_LOAD_AUX);
     }
-    if (kNsqTail && __builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kNsqTail) { // (whole waves past the halo skip it)
+    if (kNsqTail && IT0 <= kNsqFull && IT1 > kNsqFull &&
+        __builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kNsqTail) { // (whole waves past the halo skip it)
         ra[kNsqFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kNsqFull * (kThreads * 16), ADSB_LOAD_AUX);
         rb[kNsqFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kNsqFull * (kThreads * 16) + 2 * kNsqHalf, ADSB_LOAD_AUX);
     }
@@ -858,7 +867,7 @@ __device__ __forceinline__ bool nsq_image_to_lds(const u32x4 (&ra)[kNsqIters], c
 {
     uint32_t lo = 0x7BFF7BFFu; // largest finite pattern
     const uint32_t q_t = tid * 8;
-    uint32_t *dst = img + q_t + 4 * (q_t >> 6);
+    uint32_t *dst = img + nsq_phys(q_t);
     auto sweep = [&](const int it, const bool store) {
         uint32_t d[8];
         nsq_pack16(ra[it], rb[it], d);
@@ -899,6 +908,18 @@ __device__ __forceinline__ uint32_t nsq_root(uint32_t v) // floor(sqrt(v - 72)),
     return (uint32_t)__builtin_amdgcn_sqrtf((float)v - ((float)kNsqBias - 0.5f));
 }
 
+#ifndef ADSB_NSQ_AHEAD
+#define ADSB_NSQ_AHEAD 12 // granules of four pairs resident ahead of the current block in the nsq gate (>= 8)
+#endif
+#ifndef ADSB_NSQ_TPW
+#define ADSB_NSQ_TPW 1
+#endif
+constexpr int kNsqTilesPerWg = ADSB_NSQ_TPW; // consecutive tiles per workgroup of the nsq scan (see demod_tiles)
+#ifndef ADSB_NSQ_EARLY
+#define ADSB_NSQ_EARLY 2
+#endif
+constexpr int kNsqEarly = ADSB_NSQ_EARLY;    // sweeps of the next tile whose loads are issued before the gate (TPW > 1)
+
 template <bool F16OK>
 __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *cand, uint16_t *list, uint32_t *count,
                                                const uint32_t tid, const uint32_t n_valid)
@@ -907,12 +928,12 @@ __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *ca
     uint32_t *candA = cand + tid, *candB = cand + (tid + NT);
     *candA = 0u;
     *candB = 0u;
-    // run A = offsets 32 tid + o, run B = kNsqHalf + 32 tid + o: logical dwords 32 tid + j, j < RUN + 26.  Physical:
-    // 32 tid + 4 (tid >> 1) for j < 32; the second half of an odd lane's reads lies behind the next pad.
-    const u32x4 *g0 = reinterpret_cast<const u32x4 *>(img + 32 * tid + 4 * (tid >> 1));
-    const u32x4 *g1 = g0 + 8 + (tid & 1u);
+    // run A = offsets 32 tid + o, run B = kNsqHalf + 32 tid + o: logical dwords 32 tid + j, j < RUN + 26: this lane's
+    // 32 and the first 28 of the next lane's (which may lie behind a pad)
+    const u32x4 *g0 = reinterpret_cast<const u32x4 *>(img + nsq_phys(32 * tid));
+    const u32x4 *g1 = reinterpret_cast<const u32x4 *>(img + nsq_phys(32 * tid + 32));
     constexpr int kGran = (RUN + 26 + 3) / 4; // 15 granules of four pairs
-    constexpr int kAhead = 12;                // 48 pairs resident ahead of the current block
+    constexpr int kAhead = ADSB_NSQ_AHEAD;    // 48 pairs resident ahead of the current block
     uint32_t N[kGran * 4];
     auto fetch = [&](int g) {
         const u32x4 x = g < 8 ? g0[g] : g1[g - 8];
@@ -995,14 +1016,22 @@ __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *ca
 // tile in ~10 % more VALU instructions (loop-carried registers, SGPR spills) and come out 7 % slower: in-kernel cycle
 // stamps (tools/gpu/tile_stamps.py) show the SIMDs VALU-saturated while any three of the four slots compute, so
 // filling the gaps buys nothing -- the instruction count is what bounds this kernel.
-template <int ST, int MAGMODE, int SCAN>
-__global__ __launch_bounds__(kThreads, 4) void demod_tiles(DemodArgs p)
+// TPW (nsq only): consecutive tiles one workgroup takes, one after the other.  With TPW > 1 the loads of the next
+// tile are issued as soon as phase 1 has consumed the registers of the current one and stay in flight through its gate
+// and slice: the workgroup no longer waits a whole HBM round trip per tile, which at four waves per SIMD (the image
+// holds 2 bytes of LDS per sample) is what kept both the VALU and the memory pipe partly idle.
+#ifndef ADSB_SCAN_WAVES
+#define ADSB_SCAN_WAVES 4 // waves per SIMD the register allocation is held to (the LDS image allows 4 workgroups per CU)
+#endif
+template <int ST, int MAGMODE, int SCAN, int TPW = 1>
+__global__ __launch_bounds__(kThreads, ADSB_SCAN_WAVES) void demod_tiles(DemodArgs p)
 {
     typedef Lds<ST, SCAN> L;
     typedef TileCfg<ST> TC; // tile length of this sample type
     typedef typename L::mag_t mag_t;
     constexpr bool NSQ = L::kNsq;
     static_assert(kThreads / 64 <= 4, "misc[4 + wave] must stay below misc[8]");
+    static_assert(TPW == 1 || NSQ, "several tiles per workgroup: nsq scan only");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
     mag_t *mag = reinterpret_cast<mag_t *>(smem);
@@ -1011,49 +1040,69 @@ __global__ __launch_bounds__(kThreads, 4) void demod_tiles(DemodArgs p)
     uint16_t *list = reinterpret_cast<uint16_t *>(smem + L::kOffList);
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
 
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid0 = threadIdx.x;
 
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
 #if ADSB_TILE_STAMPS
+    const uint32_t tid = tid0, wave = tid0 >> 6;
     unsigned long long ts_prev = 0;
     uint32_t ts_seg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     ts_seg[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     TSTAMP(-1);
     ts_seg[8] = (uint32_t)ts_prev; // s_memtime next to the s_memrealtime above: the shader clock under this load
 #endif
-    {
-        const uint32_t tile = p.tile_first + blockIdx.x;
+    const uint32_t tile_first = p.tile_first + blockIdx.x * TPW;
+    const uint32_t tile_end = p.tile_first + p.tile_count;
+    // [phase:1 magnitude (loads, stores)]
+    // ---- phase 1, first half: the loads go out before anything else ------------------------------------------------
+    u32x4 raw[NSQ ? 1 : P1<ST>::kIters];
+    u32x4 raw_a[NSQ ? kNsqIters : 1], raw_b[NSQ ? kNsqIters : 1];
+    if constexpr (NSQ) nsq_issue_loads(p, tile_pos<TC::kTileT>(p, tile_first), tid0, raw_a, raw_b);
+    else issue_tile_loads<ST>(p, tile_pos<TC::kTileT>(p, tile_first), true, tid0, raw);
+    TSTAMP(0); // prologue, loads issued
+    if (tid0 == 0 && blockIdx.x == 0) {
+        p.hdr->retry = 0;
+        if (p.count_groups) { // first pass of a launch: the ordering pass ORs this launch's flags in
+            p.hdr->flags = 0;
+            if (p.hdr_pub) p.hdr_pub[2] = 0;
+        }
+    }
+#pragma unroll 1
+    for (int tk = 0; tk < TPW; ++tk) {
+        const uint32_t tile = tile_first + tk;
+        if (TPW > 1 && tile >= tile_end) break; // (workgroup-uniform)
+#if !ADSB_TILE_STAMPS
+        // With several tiles per workgroup everything derived from the thread index is loop-invariant; hipcc would
+        // hoist it all (addresses, lane constants of three phases) and keep it live through the whole tile: 128
+        // VGPRs and spills.  An opaque copy per iteration makes it recompute the few values where they are used.
+        uint32_t tid = tid0;
+        if constexpr (TPW > 1) asm volatile("" : "+v"(tid));
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+#else
+        const uint32_t lane = tid & 63;
+#endif
         const TilePos tp = tile_pos<TC::kTileT>(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
-
-        // [phase:1 magnitude (loads, stores)]
-        // ---- phase 1: raw IQ -> the LDS image; the loads go out before anything else ----------------------------
-        u32x4 raw[NSQ ? 1 : P1<ST>::kIters];
-        u32x4 raw_a[NSQ ? kNsqIters : 1], raw_b[NSQ ? kNsqIters : 1];
-        if constexpr (NSQ) nsq_issue_loads(p, tp, tid, raw_a, raw_b);
-        else issue_tile_loads<ST>(p, tp, true, tid, raw);
-        TSTAMP(0); // prologue, loads issued
         if (tid == 0) {
             misc[8] = 0;  // valid-frame counter
             misc[12] = 0; // survivor counter
-            if (blockIdx.x == 0) {
-                p.hdr->retry = 0;
-                if (p.count_groups) { // first pass of a launch: the ordering pass ORs this launch's flags in
-                    p.hdr->flags = 0;
-                    if (p.hdr_pub) p.hdr_pub[2] = 0;
-                }
-            }
         }
 #if ADSB_TILE_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic build only) the whole wait for the loads ...
         TSTAMP(6);                                       // ... as its own segment
 #endif
+        // ---- phase 1, second half: raw IQ -> the LDS image ---------------------------------------------------
         bool wave_big;
         if constexpr (NSQ) wave_big = nsq_image_to_lds(raw_a, raw_b, img, tid);
         else wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
         if ((NSQ || ST == ADSB_SAMPLE_I16) && lane == 0) misc[4 + wave] = wave_big ? 1u : 0u; // (every wave writes its own word)
+        // the next tile's samples: the first kNsqEarly sweeps are in flight through this tile's gate and slice, the
+        // rest -- the gate needs the registers -- from the end of the gate on
+        const bool more = TPW > 1 && tk + 1 < TPW && tile + 1 < tile_end; // (workgroup-uniform)
+        if constexpr (TPW > 1) {
+            if (more) nsq_issue_loads<0, kNsqEarly>(p, tile_pos<TC::kTileT>(p, tile + 1), tid, raw_a, raw_b);
+        }
         TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
         TSTAMP(2); // barrier
@@ -1083,12 +1132,15 @@ __global__ __launch_bounds__(kThreads, 4) void demod_tiles(DemodArgs p)
         }
 #endif
         TSTAMP(3); // phase 2
+        if constexpr (TPW > 1) {
+            if (more) nsq_issue_loads<kNsqEarly, kNsqIters>(p, tile_pos<TC::kTileT>(p, tile + 1), tid, raw_a, raw_b);
+        }
         __syncthreads();
         TSTAMP(4); // barrier
 
         // [phase:3 hand-over: slots, offsets, sliced bytes]
         // ---- phase 3: PPM slice of the gate survivors; the CRC stage is a kernel of its own --------------------
-        // Every survivor gets a frame slot, its absolute offset and its 14 sliced bytes (the magnitudes are here, in
+        // Every survivor gets a frame slot, its absolute offset and its 14 sliced bytes (the image is here, in
         // LDS).  CRC-24, repair, ordering inside the tile and the valid-frame count are finish_candidates' work, one
         // LANE per survivor instead of sixteen.  (With the whole decode in this kernel a tile's 33 KB of LDS were
         // held through a latency-bound epilogue: 19 % of the kernel time for 13 % of its instructions.)
@@ -1133,15 +1185,17 @@ __global__ __launch_bounds__(kThreads, 4) void demod_tiles(DemodArgs p)
         // 16-lane groups slice one survivor each, one lane per frame byte, and store offset + 14 raw bytes (no CRC
         // verdict yet) into the survivor's slot: 16 survivors per workgroup round
         const uint32_t g = tid >> 4, l = tid & 15;
+        auto slice_one = [&](uint32_t off) {
+            if constexpr (NSQ) return nsq_slice_byte(img, off, l);
+            else return slice_byte<ST>(mag, off, l < 14 ? l : 13);
+        };
         auto slice_round = [&](uint32_t slot0, uint32_t ncl) {
             for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
                 if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a survivor
                 const uint32_t ci = r + g;
                 const bool have = ci < ncl; // uniform within the 16-lane group
                 const uint32_t off = have ? list[ci] : 0u;
-                uint32_t byte;
-                if constexpr (NSQ) byte = nsq_slice_byte(img, off, l);
-                else byte = slice_byte<ST>(mag, off, l < 14 ? l : 13);
+                const uint32_t byte = slice_one(off);
                 if (have) {
                     unsigned char *rec = reinterpret_cast<unsigned char *>(p.slots + (size_t)slot0 + ci);
                     const uint64_t o64 = abs0 + off;
@@ -1182,16 +1236,13 @@ __global__ __launch_bounds__(kThreads, 4) void demod_tiles(DemodArgs p)
                     slice_round(base_slot + chunk, ncl); // (ordered when dense; 33..64 survivors: unordered like the simple case)
                 } else {
                     // The slot store is full (pathological input: SURVEY F8).  The host re-plans from exact counts,
-                    // so this tile's survivors are decoded HERE, from the magnitudes in LDS, only to be counted.
+                    // so this tile's survivors are decoded HERE, from the image in LDS, only to be counted.
                     for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
                         if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a candidate
                         const uint32_t ci = r + g;
                         const bool have = ci < ncl; // uniform within the 16-lane group
                         const uint32_t off = have ? list[ci] : 0u;
-                        uint32_t byte;
-                        if constexpr (NSQ) byte = nsq_slice_byte(img, off, l);
-                        else byte = slice_byte<ST>(mag, off, l < 14 ? l : 13);
-                        const bool valid = count_candidate(have, byte, l, lane);
+                        const bool valid = count_candidate(have, slice_one(off), l, lane);
                         if (valid && l == 0) atomicAdd(&misc[8], 1u);
                     }
                 }
@@ -1216,6 +1267,7 @@ __global__ __launch_bounds__(kThreads, 4) void demod_tiles(DemodArgs p)
             e.decoded = base_slot == kNoBase ? 1u : 0u;
             p.seg[tile] = e; // (finish_candidates sums the groups' counters, this tile's count included)
         }
+        if constexpr (TPW > 1) __syncthreads(); // the image, the list and the counters are the next tile's from here on
     }
     // [phase:end]
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
@@ -1487,7 +1539,8 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
 {
     if (a.tile_count == 0) return hipSuccess;
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
-        hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq>), dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
+        hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq, kNsqTilesPerWg>),
+                              dim3((a.tile_count + kNsqTilesPerWg - 1) / kNsqTilesPerWg), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);

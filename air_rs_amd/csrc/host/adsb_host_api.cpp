@@ -83,8 +83,8 @@ static int run_pipeline(adsb_ctx *ctx, const void *data, size_t n, size_t chunk_
     Thread2Stats st;
     std::string printed;
 
-    std::thread t1([tx = std::move(raw.first), d = std::move(all), chunk_len, send_tail]() mutable {
-        playback_thread<T>(std::move(tx), std::move(d), chunk_len, false, send_tail);
+    std::thread t1([tx = std::move(raw.first), d = std::move(all), chunk_len, send_tail, carry_over]() mutable {
+        playback_thread<T>(std::move(tx), std::move(d), chunk_len, false, send_tail, carry_over ? 0 : 240);
     });
     std::thread t2([&, rx = std::move(raw.second), tx = std::move(msgs.first)]() mutable {
         st = process_sdr_data_thread<T>(ctx, std::move(rx), std::move(tx), &log, chunk_len + 240, carry_over, chunk_len);

@@ -133,10 +133,22 @@ std::string AdsbPacket::to_string(const char *time_text) const
     if (time_text) {
         s += line("Processed Time  : ", time_text);
     } else {
-        std::time_t t = std::chrono::system_clock::to_time_t(time_processed);
+        // chrono's `impl Display for DateTime<Local>` (what packet.rs:94 prints, e.g.
+        // "2025-07-26 07:47:16.818387100 +12:00"): date, time, the fraction in 0 / 3 / 6 / 9 digits -- the fewest
+        // that lose nothing -- and the UTC offset with a colon
+        using namespace std::chrono;
+        const auto since = time_processed.time_since_epoch();
+        std::time_t t = system_clock::to_time_t(time_processed);
+        const long long ns = duration_cast<nanoseconds>(since - duration_cast<seconds>(since)).count();
         std::tm tmv{};
         localtime_r(&t, &tmv);
-        std::strftime(buf, sizeof buf, "%Y-%m-%d %H:%M:%S %z", &tmv);
+        size_t k = std::strftime(buf, sizeof buf, "%Y-%m-%d %H:%M:%S", &tmv);
+        if (ns % 1000000 == 0 && ns != 0) k += (size_t)std::snprintf(buf + k, sizeof buf - k, ".%03lld", ns / 1000000);
+        else if (ns % 1000 == 0 && ns != 0) k += (size_t)std::snprintf(buf + k, sizeof buf - k, ".%06lld", ns / 1000);
+        else if (ns != 0) k += (size_t)std::snprintf(buf + k, sizeof buf - k, ".%09lld", ns);
+        char off[8];
+        std::strftime(off, sizeof off, "%z", &tmv); // +hhmm
+        std::snprintf(buf + k, sizeof buf - k, " %.3s:%.2s", off, off + 3);
         s += line("Processed Time  : ", buf);
     }
     s += line("Message Type    : ", std::to_string(msg_type));

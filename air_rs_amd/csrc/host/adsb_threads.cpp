@@ -41,7 +41,7 @@ bool save_data(const IqBufI16 &data, const std::string &filename, std::string &e
 
 template <typename T>
 void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>> data, size_t chunk_len, bool pace,
-                     bool send_tail)
+                     bool send_tail, size_t min_tail)
 {
     // The reference computes `data.len()-20000` in usize: a shorter file underflows (panic in
     // debug builds).  Here that case sends nothing (or, with send_tail, the whole file as one buffer).
@@ -55,7 +55,10 @@ void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>>
         }
         if (pace) std::this_thread::sleep_for(std::chrono::duration<double>(1e4 / 2e6));
     }
-    if (send_tail && i < data.size()) { // what adsb.rs:77's strict `<` never sends
+    // what adsb.rs:77's strict `<` never sends.  (A tail too short to be a buffer of its own for the consumer -- fewer
+    // than 240 samples when thread 2 runs with the reference's per-buffer semantics, where it would be the panic of
+    // adsb.rs:98 -- is not sent: there is no offset in it to examine.)
+    if (send_tail && i < data.size() && data.size() - i >= min_tail) {
         std::vector<Complex<T>> buf(data.begin() + i, data.end());
         if (!tx.send(std::move(buf))) {
             std::printf("Raw sdr receiver is dropped\n");
@@ -116,8 +119,26 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
         }
         return !closed;
     };
-    while (auto buf = rx.recv()) {
-        rc = buf->size() > max_chunk ? ADSB_E_CAPACITY : adsb_feed_push(feed, buf->data(), buf->size());
+    // The reference sends a buffer's packets before its next recv() (adsb.rs:95-116).  Here up to two buffers are in
+    // flight on the GPU, but nothing is held back: while the input channel is empty the thread waits for the GPU
+    // instead (a stalled source cannot strand the last buffer's frames), and after every push whatever has already
+    // finished is handed on.
+    for (;;) {
+        std::vector<Complex<T>> buf;
+        int got = rx.try_recv(&buf);
+        if (got == 1) { // Err(Empty)
+            if (adsb_feed_in_flight(feed) > 0) {
+                if (!pop_and_send()) break; // (blocks on the GPU, not on the source)
+                continue;
+            }
+            auto b = rx.recv(); // nothing in flight: block on the source like the reference
+            if (!b) break;
+            buf = std::move(*b);
+        } else if (got == 2) {
+            break; // every sender dropped and the queue drained (adsb.rs:95 ends the loop)
+        }
+        if (buf.size() > max_chunk) rc = ADSB_E_CAPACITY;
+        else rc = adsb_feed_push(feed, buf.data(), buf.size());
         if (rc != ADSB_OK) {
             // ADSB_E_SHORT is where the reference panics (adsb.rs:98); any error ends the thread.
             st.last_error = rc;
@@ -125,7 +146,9 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
             break;
         }
         st.buffers++;
-        if (adsb_feed_in_flight(feed) == 2 && !pop_and_send()) break;
+        while (!closed && (adsb_feed_in_flight(feed) == 2 || (adsb_feed_in_flight(feed) > 0 && adsb_feed_ready(feed) == 1)))
+            if (!pop_and_send()) break;
+        if (closed) break;
     }
     while (!closed && adsb_feed_in_flight(feed) > 0)
         if (!pop_and_send()) break;
@@ -135,8 +158,8 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
     return st;
 }
 
-template void playback_thread<int16_t>(Sender<IqBufI16>, IqBufI16, size_t, bool, bool);
-template void playback_thread<int8_t>(Sender<IqBufI8>, IqBufI8, size_t, bool, bool);
+template void playback_thread<int16_t>(Sender<IqBufI16>, IqBufI16, size_t, bool, bool, size_t);
+template void playback_thread<int8_t>(Sender<IqBufI8>, IqBufI8, size_t, bool, bool, size_t);
 template Thread2Stats process_sdr_data_thread<int16_t>(adsb_ctx *, Receiver<IqBufI16>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t, bool, size_t);
 template Thread2Stats process_sdr_data_thread<int8_t>(adsb_ctx *, Receiver<IqBufI8>, Sender<AdsbPacket>, std::vector<adsb_frame> *, size_t, bool, size_t);
 

@@ -25,10 +25,11 @@ bool save_data(const IqBufI16 &data, const std::string &filename, std::string &e
 
 // adsb.rs:75-89: 20 000-sample buffers, `while i < len - 20000` (the tail is never sent), then
 // drop(tx).  pace=true keeps the reference's 5 ms sleep per buffer.  send_tail=true (NOT reference behaviour,
-// SURVEY 8f-1) also sends what the reference's strict `<` leaves behind: the last full or partial chunk.
+// SURVEY 8f-1) also sends what the reference's strict `<` leaves behind: the last full or partial chunk -- unless it
+// is shorter than min_tail samples (240 when the consumer demodulates buffer by buffer: such a tail holds no offset).
 template <typename T>
 void playback_thread(Sender<std::vector<Complex<T>>> tx, std::vector<Complex<T>> data,
-                     size_t chunk_len = 20000, bool pace = false, bool send_tail = false);
+                     size_t chunk_len = 20000, bool pace = false, bool send_tail = false, size_t min_tail = 0);
 
 // adsb.rs:92-122: for every received buffer, demodulate and send one AdsbPacket per frame, in
 // ascending offset order; return when either channel closes; drop(tx) at the end.

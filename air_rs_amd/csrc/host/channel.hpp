@@ -104,6 +104,18 @@ public:
         return v;
     }
 
+    // `try_recv()`: 0 = Ok(v) (written to *out), 1 = Err(Empty), 2 = Err(Disconnected)
+    int try_recv(T *out)
+    {
+        std::lock_guard<std::mutex> g(st_->mu);
+        if (!st_->q.empty()) {
+            *out = std::move(st_->q.front());
+            st_->q.pop_front();
+            return 0;
+        }
+        return st_->senders == 0 ? 2 : 1;
+    }
+
 private:
     std::shared_ptr<ChannelState<T>> st_;
 };

@@ -151,8 +151,8 @@ class AdsbDemod:
 
     @property
     def scan(self):
-        """'nsq' (the product's i8 scan kernel: gate on I^2+Q^2) or 'root' (floor(sqrt) per sample: CS16 always;
-        i8 when ADSB_SCAN=root was set at creation, for A/B measurements)."""
+        """'root' (floor(sqrt) per sample: the product's scan kernel, and CS16's only one) or 'nsq' (the A/B kernel
+        whose gate works on I^2+Q^2: i8 contexts created with ADSB_SCAN=nsq in the environment)."""
         return "root" if self._lib.adsb_debug_scan(self._h) == 1 else "nsq"
 
     def pool_limit(self, on=True):
@@ -352,6 +352,69 @@ class AdsbDemod:
         return frames[:min(n_frames.value, max_frames)].copy(), n_buf.value
 
 
+def group_plan(n_samples, n_members):
+    """adsb_group_plan: [(first_sample, n_samples, n_offsets)] per member."""
+    sh = (L.AdsbGroupShard * n_members)()
+    L.check(L.load().adsb_group_plan(int(n_samples), int(n_members), sh), "adsb_group_plan")
+    return [(s.first_sample, s.n_samples, s.n_offsets) for s in sh]
+
+
+class AdsbGroup:
+    """adsb_group_*: one buffer time-sharded over several contexts / devices behind one call (native: no torch,
+    no launcher).  `devices` may repeat an ordinal (several contexts on one GPU)."""
+
+    def __init__(self, devices, sample_type=L.ADSB_SAMPLE_I8, max_samples=1 << 20, max_out=1 << 16, root=0,
+                 host_staging=True):
+        self._lib = L.load()
+        self._devs = (C.c_int32 * len(devices))(*devices)
+        cfg = L.AdsbGroupCfg(L.ADSB_ABI_VERSION, sample_type, len(devices), root, self._devs, max_samples, max_out,
+                             1 if host_staging else 0, 0)
+        h = C.c_void_p()
+        L.check(self._lib.adsb_group_create(C.byref(cfg), C.byref(h)), "adsb_group_create")
+        self._h, self.n, self.max_out, self.sample_type = h, len(devices), max_out, sample_type
+        self._np_dtype = np.int8 if sample_type == L.ADSB_SAMPLE_I8 else np.int16
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.adsb_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def demod(self, iq, max_out=None):
+        """One host buffer through all members: (frames, flags)."""
+        iq = np.ascontiguousarray(iq, dtype=self._np_dtype)
+        n = iq.shape[0] if iq.ndim == 2 else iq.size // 2
+        cap = self.max_out if max_out is None else max_out
+        out = np.zeros(max(cap, 1), dtype=FRAME_DTYPE)
+        n_out, flags = C.c_size_t(), C.c_uint32()
+        L.check(self._lib.adsb_group_demod(self._h, iq.ctypes.data, n, out.ctypes.data_as(C.POINTER(L.AdsbFrame)), cap,
+                                           C.byref(n_out), C.byref(flags)), "adsb_group_demod")
+        return out[:n_out.value].copy(), flags.value
+
+    def demod_device_async(self, dev_ptrs, n_samples):
+        arr = (C.c_void_p * self.n)(*[int(p) if p else None for p in dev_ptrs])
+        L.check(self._lib.adsb_group_demod_device_async(self._h, arr, int(n_samples)), "adsb_group_demod_device_async")
+
+    def fetch(self, max_out=None):
+        cap = self.max_out if max_out is None else max_out
+        out = np.zeros(max(cap, 1), dtype=FRAME_DTYPE)
+        n_out, total, flags = C.c_size_t(), C.c_uint64(), C.c_uint32()
+        L.check(self._lib.adsb_group_fetch(self._h, out.ctypes.data_as(C.POINTER(L.AdsbFrame)), cap, C.byref(n_out),
+                                           C.byref(total), C.byref(flags)), "adsb_group_fetch")
+        return out[:n_out.value].copy(), total.value, flags.value
+
+    def result_device(self):
+        """(blob device pointer, hipStream_t the merge was enqueued on)."""
+        blob, stream = C.c_void_p(), C.c_void_p()
+        L.check(self._lib.adsb_group_result_device(self._h, C.byref(blob), C.byref(stream)), "adsb_group_result_device")
+        return blob.value, stream.value
+
+
 class Feed:
     """Streaming front end (adsb_feed_*): push host buffers, pop their frames in order; two may be in flight."""
 
@@ -376,6 +439,14 @@ class Feed:
     @property
     def in_flight(self):
         return self._lib.adsb_feed_in_flight(self._h)
+
+    @property
+    def ready(self):
+        """True when pop() would not wait for the GPU."""
+        r = self._lib.adsb_feed_ready(self._h)
+        if r < 0 or r > 1:
+            raise L.AdsbError(r, "adsb_feed_ready")
+        return bool(r)
 
     def push(self, iq):
         iq = np.ascontiguousarray(iq, dtype=self._dem._np_dtype)

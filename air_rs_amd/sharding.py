@@ -119,6 +119,12 @@ class BucketGather:
     buckets alternate.  Offsets are absolute (adsb_set_stream_base), so rank 0 concatenates the lists of one
     launch in rank order and has the globally ordered list.
 
+    Stream contract (device tensors): the launches that fill the slots must be enqueued on torch's CURRENT stream at
+    begin_launch() / end_launch() time -- i.e. the AdsbDemod context must have been created on that stream
+    (`stream=torch.cuda.current_stream().cuda_stream`, as bench.py does).  Re-use of a bucket half is ordered behind
+    the gather that still reads it by `pending.wait()`, which makes the current stream wait; a context with a stream
+    of its own would overwrite a slot RCCL is still reading.
+
     Use, per launch:   ptr = bg.begin_launch()         # slot to write; waits (stream-side) for the gather
                        ...enqueue the launch...        #   that still reads this half of the double buffer
                        bg.end_launch(wait_results)     # full bucket -> gather
@@ -247,8 +253,16 @@ class BucketGather:
         return self.first[bk] + self.filled[bk] - 1
 
 
+ADSB_FLAG_INCOMPLETE = 0x2  # include/adsb_hip.h
+
+
 def merge_rank_lists(per_rank):
-    """Concatenate one launch's per-rank lists (absolute offsets) in rank order; asserts global order."""
+    """Concatenate one launch's per-rank lists (absolute offsets) in rank order; asserts global order.  A list
+    whose payload header carries ADSB_FLAG_INCOMPLETE has holes (slot-pool overflow on the producing rank, which
+    must call fetch_counts() before its bucket is flushed): refused, never merged silently."""
+    for r, (_, _, fl, _) in enumerate(per_rank):
+        if fl & ADSB_FLAG_INCOMPLETE:
+            raise ValueError(f"rank {r}'s list is incomplete (ADSB_FLAG_INCOMPLETE): the producer must repair it with fetch_counts() first")
     parts = [f for (_, _, _, f) in per_rank]
     merged = np.concatenate(parts) if parts else np.zeros(0, dtype=FRAME_DTYPE)
     if len(merged) > 1:

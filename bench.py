@@ -104,8 +104,8 @@ def main():
                     help="split the per-GPU buffer into this many independent channels handled by ONE launch "
                          "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
     ap.add_argument("--scan", choices=["default", "nsq", "root"], default="default",
-                    help="i8 scan kernel: nsq = the gate on I^2+Q^2 (the product's), root = floor(sqrt) per sample (the "
-                         "round-1/2 kernel, for A/B); default = the library's default (ADSB_SCAN in the environment is honoured)")
+                    help="i8 scan kernel: root = floor(sqrt) per sample (the product's), nsq = the gate on I^2+Q^2 (the round-3 "
+                         "A/B kernel); default = the library's default (ADSB_SCAN in the environment is honoured)")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the multi-rank frame-list gather even with one rank (testing)")
     args = ap.parse_args()
@@ -298,7 +298,7 @@ def main():
         # inside this process: the figure is the committed one for this exact workload and says so; null otherwise.
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc) and n == 1 << (29 if bps == 2 else 28) and nch == 1 and (bps == 4 or dem.scan == "nsq"):
+        if os.path.exists(pmc) and n == 1 << (29 if bps == 2 else 28) and nch == 1 and dem.scan == "root":
             try:
                 pj = json.load(open(pmc))
                 key = "demod_tiles_hbm_bytes_per_launch" if bps == 2 else "demod_tiles_i16_hbm_bytes_per_launch"

@@ -193,6 +193,10 @@ int adsb_feed_push(adsb_feed *feed, const void *iq_host, size_t n_samples);
 int adsb_feed_pop(adsb_feed *feed, adsb_frame *out, size_t max_out, size_t *n_out, uint32_t *flags,
                   uint64_t *first_sample);
 int adsb_feed_in_flight(const adsb_feed *feed); /* 0, 1 or 2 */
+/* 1: adsb_feed_pop() would return the oldest buffer's frames without waiting for the GPU; 0: it would wait;
+ * ADSB_E_STATE: nothing is in flight.  Lets a consumer hand packets on as soon as they exist instead of one buffer
+ * late (the reference sends a buffer's packets before its next recv(), src/adsb.rs:95-116). */
+int adsb_feed_ready(adsb_feed *feed);
 void adsb_feed_close(adsb_feed *feed);
 
 /*
@@ -256,6 +260,57 @@ int adsb_track_device(adsb_ctx *ctx, double seconds_per_sample);
 int adsb_fetch_track(adsb_ctx *ctx, adsb_track_point *points, size_t max_points, size_t *n_points,
                      adsb_aircraft_record *aircraft, size_t max_aircraft, size_t *n_aircraft);
 
+/*
+ * ---- several GPUs behind one call ---------------------------------------------------------
+ * The reference's thread 2 is one function on one thread (src/adsb.rs:92, spawned at adsb.rs:147); a group is the
+ * drop-in for that function when the buffer should be spread over N devices: one context per member, the offsets
+ * [0, n - 240) of the buffer split evenly in member order, every member reading its own offsets plus a 239-sample
+ * halo (neighbouring slices overlap by 240 samples: the window is 16 + 224, adsb.rs:98,106).  Every offset is
+ * independent (adsb.rs:113 skips nothing), so the members' lists, which carry absolute offsets, concatenated in
+ * member order ARE the single-context list: same frames, same order.  The lists meet in the root member's device
+ * memory (hipMemcpyPeerAsync) as [ uint64 n_out | uint64 total_found | uint64 flags | uint64 0 | adsb_frame[...] ].
+ * Members may name the same device more than once (several contexts on one GPU).  Like a context, a group is
+ * not thread-safe: one calling thread.
+ */
+typedef struct adsb_group adsb_group;
+typedef struct adsb_group_cfg {
+    uint32_t       abi_version;  /* ADSB_ABI_VERSION                                                       */
+    int32_t        sample_type;  /* ADSB_SAMPLE_I8 / ADSB_SAMPLE_I16                                       */
+    uint32_t       n_members;    /* 1..64 contexts                                                         */
+    uint32_t       root;         /* index of the member whose device receives the merged list              */
+    const int32_t *devices;      /* [n_members] HIP device ordinal of each member                          */
+    uint64_t       max_samples;  /* of the WHOLE buffer                                                    */
+    uint64_t       max_out;      /* frames kept per launch, whole buffer                                   */
+    uint32_t       host_staging; /* 1: per-member device staging so the host-pointer entry points work     */
+    uint32_t       reserved;
+} adsb_group_cfg;
+typedef struct adsb_group_shard { /* what one member works on */
+    uint64_t first_sample;       /* its slice starts here (a multiple of 8 samples) ...                    */
+    uint64_t n_samples;          /* ... and is this long: n_offsets + 240; 0 = the member has nothing      */
+    uint64_t n_offsets;          /* it owns the offsets [first_sample, first_sample + n_offsets)           */
+} adsb_group_shard;
+int adsb_group_create(const adsb_group_cfg *cfg, adsb_group **out_group);
+void adsb_group_destroy(adsb_group *group);
+uint32_t adsb_group_size(const adsb_group *group);
+adsb_ctx *adsb_group_member(adsb_group *group, uint32_t index); /* e.g. for adsb_synth_fill_device on its device */
+/* The split a group of n_members makes of an n_samples buffer (ADSB_E_SHORT below 240 samples). */
+int adsb_group_plan(uint64_t n_samples, uint32_t n_members, adsb_group_shard *shards);
+/* One iteration of the reference loop (adsb.rs:95-116) for one received buffer in HOST memory, spread over the
+ * members: like adsb_demod().  Blocking.  Requires cfg.host_staging. */
+int adsb_group_demod(adsb_group *group, const void *iq_host, size_t n_samples, adsb_frame *out, size_t max_out,
+                     size_t *n_out, uint32_t *flags);
+/* The same without waiting (copies and kernels are enqueued on the members' streams). */
+int adsb_group_demod_host_async(adsb_group *group, const void *iq_host, size_t n_samples);
+/* Device-resident form: iq_dev[i] = member i's slice (adsb_group_plan: samples [first_sample, first_sample +
+ * n_samples) of the buffer) in ITS device's memory, 16-byte aligned; NULL where n_samples is 0. */
+int adsb_group_demod_device_async(adsb_group *group, const void *const *iq_dev, size_t n_samples);
+/* Waits for the members, merges, copies the list to the host (ascending offset). */
+int adsb_group_fetch(adsb_group *group, adsb_frame *out, size_t max_out, size_t *n_out, uint64_t *total_found,
+                     uint32_t *flags);
+/* Waits for the members' counts and enqueues the merge; *blob_dev = the merged [header | frames] blob on the root
+ * member's device, complete once *stream (hipStream_t, on that device) has drained. */
+int adsb_group_result_device(adsb_group *group, const void **blob_dev, void **stream);
+
 /* The stream the ctx enqueues on (hipStream_t as void*). */
 void *adsb_stream(adsb_ctx *ctx);
 /* cfg.sample_type the ctx was created with (ADSB_SAMPLE_*); ADSB_E_ARG for NULL. */
@@ -295,9 +350,9 @@ int adsb_debug_nsq_values(adsb_ctx *ctx, const void *iq_host, size_t n_samples, 
  * gate + slice of the survivors) and the ordering pass but not the finishing kernel -- no survivor is CRC-checked, so
  * NO frames come out.  on = 0 restores the full path. */
 int adsb_debug_fused_pass_only(adsb_ctx *ctx, int on);
-/* Which scan kernel an i8 context launches: 0 = the gate on n = I^2+Q^2 (default), 1 = the round-1/2 kernel with
- * floor(sqrt) per sample, selected by ADSB_SCAN=root in the environment at adsb_create (A/B measurements; same
- * results).  Always 1 for CS16 (one kernel). */
+/* Which scan kernel an i8 context launches: 1 = floor(sqrt) per sample (default), 0 = the A/B kernel whose gate
+ * works on n = I^2+Q^2, selected by ADSB_SCAN=nsq in the environment at adsb_create (same results; DESIGN.md
+ * section 5.3 has the measurements).  Always 1 for CS16 (one kernel). */
 int adsb_debug_scan(adsb_ctx *ctx);
 /* Test knob: with on != 0 the shared slot pool of the following launches hands out nothing, so every tile with
  * more gate survivors than its own 32 slots loses them: the launch's list comes out with ADSB_FLAG_INCOMPLETE (for

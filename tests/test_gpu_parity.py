@@ -10,11 +10,11 @@ import air_rs_amd as A
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["nsq", "root"], autouse=True)
+@pytest.fixture(scope="module", params=["root", "nsq"], autouse=True)
 def scan_kind(request):
-    """Every i8 test of this module runs once per i8 scan kernel: "nsq" (the product's: the gate on I^2+Q^2) and
-    "root" (the round-1/2 kernel with floor(sqrt) per sample, kept for A/B measurements -- it must stay bit-exact
-    too).  ADSB_SCAN is read by adsb_create."""
+    """Every i8 test of this module runs once per i8 scan kernel: "root" (the product's: floor(sqrt) per sample) and
+    "nsq" (the round-3 A/B kernel whose gate works on I^2+Q^2 -- kept selectable, so it must stay bit-exact too).
+    ADSB_SCAN is read by adsb_create."""
     old = os.environ.get("ADSB_SCAN")
     os.environ["ADSB_SCAN"] = request.param
     yield request.param
@@ -274,7 +274,7 @@ def test_large_streaming_buffer_sampled(gpu, oracle, scan_kind):
     # the size-independent property that any sub-range demodulated alone gives the same frames
     # (every offset is independent).
     import torch
-    if scan_kind != "nsq":
+    if scan_kind != "root":
         pytest.skip("the 5 GiB buffer runs once, through the product's scan kernel")
     n = 5 * (1 << 29)  # 2.68 G samples = 5 GiB: byte offsets cross 2^32
     cfg = A.synth_default(seed=333)

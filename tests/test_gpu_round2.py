@@ -127,14 +127,14 @@ def test_zero_copy_consumer_sees_incomplete_flag_and_repair(gpu, oracle):
 
 
 def test_scan_kernel_selection(gpu, monkeypatch):
-    """ADSB_SCAN at adsb_create: default and "nsq" = the product's i8 scan kernel, "root" = the A/B kernel, anything
+    """ADSB_SCAN at adsb_create: default and "root" = the product's i8 scan kernel, "nsq" = the A/B kernel, anything
     else is refused; CS16 has one kernel."""
     monkeypatch.delenv("ADSB_SCAN", raising=False)
     with A.AdsbDemod(max_samples=4096, max_out=16) as d:
-        assert d.scan == "nsq"
-    monkeypatch.setenv("ADSB_SCAN", "root")
-    with A.AdsbDemod(max_samples=4096, max_out=16) as d:
         assert d.scan == "root"
+    monkeypatch.setenv("ADSB_SCAN", "nsq")
+    with A.AdsbDemod(max_samples=4096, max_out=16) as d:
+        assert d.scan == "nsq"
     monkeypatch.setenv("ADSB_SCAN", "stream")
     with pytest.raises(A.AdsbError) as e:
         A.AdsbDemod(max_samples=4096, max_out=16)

@@ -6,7 +6,7 @@ the per-rank demodulator is the CPU oracle standing in as a *checker stub* for t
     same calls; only the backend and the device of the tensors differ) -- incl. partial buckets, a step count
     that is not a multiple of the bucket size, and frame CONTENT against the single-buffer result,
   * sharding.gather_frame_lists (the one-shot variable-length gather, a convenience for callers without buckets).
-The `-m gpu` tier runs the same shard plans through the HIP path on one device (tests/test_gpu_sharding.py)."""
+The `-m gpu` tier runs the same shard plans through the HIP path on one device (tests/test_gpu_round2.py::test_shard_plan_through_hip_equals_single_buffer and tests/test_gpu_group.py)."""
 import os
 import sys
 
