@@ -38,7 +38,7 @@ struct adsb_ctx {
         adsb_frame *slots = nullptr;     // [n_tiles_max * kQuota] fixed region, then the pool [cap_slots]
         adsb_frame *out = nullptr;       // [max_out]
         adsbk::Header *hdr = nullptr;
-        uint64_t *chan_counts = nullptr; // [max_channels]
+        uint64_t *chan_prefix = nullptr; // [max_channels + 1]: frames before each channel's first tile; last = total
         hipEvent_t k_done = nullptr, g_done = nullptr;
         bool g_pending = false;
         // the launch whose results this set holds (the streaming front end fetches the older of two launches
@@ -74,8 +74,8 @@ struct adsb_ctx {
     uint32_t launch_idx = 0;        // launches so far
     uint32_t last = 0;              // result set of the last launch
     uint32_t *out_start = nullptr;  // [n_tiles_max + 1]  (slot-overflow re-run path only)
-    uint32_t *grp = nullptr;        // three sets x (grp1[n_grp1] | grp2[n_grp2]) valid-frame counters
-    uint32_t n_grp1 = 0, n_grp2 = 0;
+    uint64_t *lb = nullptr;         // finish_order's exchange words: one per workgroup, then one per 64 workgroups
+    uint32_t lb_groups_at = 0;
     uint32_t *scratch = nullptr;    // 16 dwords: probe result, read-kernel sink
     unsigned long long *stamps = nullptr; // cycle counters of diagnostic builds (64 bytes per tile with -DADSB_TILE_STAMPS=1)
     size_t stamps_bytes = 0;
@@ -96,7 +96,7 @@ struct adsb_ctx {
 
     // timing
     int timing = 0;                 // 0 off; N: events on every N-th launch
-    hipEvent_t ev[kTimingRing][6] = {}; // scan kernel, ordering pass, decode kernel: start/end each
+    hipEvent_t ev[kTimingRing][4] = {}; // scan kernel, finishing kernel: start/end each
     bool ev_made = false;
     uint32_t ev_count = 0;
 };
@@ -144,7 +144,7 @@ extern "C" void adsb_destroy(adsb_ctx *c)
         (void)hipFree(r.slots);
         (void)hipFree(r.out);
         (void)hipFree(r.hdr);
-        (void)hipFree(r.chan_counts);
+        (void)hipFree(r.chan_prefix);
         if (r.k_done) (void)hipEventDestroy(r.k_done);
         if (r.g_done) (void)hipEventDestroy(r.g_done);
     }
@@ -157,7 +157,7 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     (void)hipFree(c->trk_n_aircraft);
     (void)hipFree(c->scratch);
     (void)hipFree(c->stamps);
-    (void)hipFree(c->grp);
+    (void)hipFree(c->lb);
     if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -196,8 +196,6 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     if (tiles * adsbk::kQuota + cfg->max_out + kTile > 0xFFFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
     c->n_tiles_max = (uint32_t)tiles;
     c->cap_slots = (uint32_t)(cfg->max_out + kTile);
-    c->n_grp1 = (c->n_tiles_max >> adsbk::kGrpShift) + 2;
-    c->n_grp2 = ((c->n_tiles_max >> (2 * adsbk::kGrpShift)) + 2) * adsbk::kGrp2Shards;
 
     int rc = ADSB_OK;
     auto fail = [&](int code) { rc = code; };
@@ -237,16 +235,18 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
                  hipMalloc((void **)&r.slots, sizeof(adsb_frame) * n_slots) == hipSuccess &&
                  hipMalloc((void **)&r.out, sizeof(adsb_frame) * (size_t)cfg->max_out) == hipSuccess &&
                  hipMalloc((void **)&r.hdr, sizeof(adsbk::Header)) == hipSuccess &&
-                 hipMalloc((void **)&r.chan_counts, sizeof(uint64_t) * cfg->max_channels) == hipSuccess &&
+                 hipMalloc((void **)&r.chan_prefix, sizeof(uint64_t) * ((size_t)cfg->max_channels + 1)) == hipSuccess &&
+                 hipMemsetAsync(r.chan_prefix, 0, sizeof(uint64_t) * ((size_t)cfg->max_channels + 1), c->stream) == hipSuccess &&
                  hipEventCreateWithFlags(&r.k_done, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
                  hipEventCreateWithFlags(&r.g_done, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
                  hipMemsetAsync(r.hdr, 0, sizeof(adsbk::Header), c->stream) == hipSuccess;
         }
-        const size_t grp_words = 3 * ((size_t)c->n_grp1 + c->n_grp2);
+        c->lb_groups_at = (uint32_t)(((size_t)c->n_tiles_max / adsbk::kFinishTilesPerWg + 2 + 63) / 64 * 64);
+        const size_t lb_words = (size_t)c->lb_groups_at + c->lb_groups_at / 64 + 64;
         ok = ok && hipMalloc((void **)&c->out_start, sizeof(uint32_t) * ((size_t)c->n_tiles_max + 1)) == hipSuccess &&
              hipMalloc((void **)&c->scratch, 64) == hipSuccess &&
-             hipMalloc((void **)&c->grp, sizeof(uint32_t) * grp_words) == hipSuccess &&
-             hipMemsetAsync(c->grp, 0, sizeof(uint32_t) * grp_words, c->stream) == hipSuccess &&
+             hipMalloc((void **)&c->lb, sizeof(uint64_t) * lb_words) == hipSuccess &&
+             hipMemsetAsync(c->lb, 0, sizeof(uint64_t) * lb_words, c->stream) == hipSuccess &&
              hipMemsetAsync(c->scratch, 0, 64, c->stream) == hipSuccess;
         if (!ok) { fail(ADSB_E_NOMEM); break; }
         if (hipHostMalloc((void **)&c->hdr_host, sizeof(adsbk::Header), hipHostMallocDefault) != hipSuccess) { fail(ADSB_E_NOMEM); break; }
@@ -297,11 +297,8 @@ extern "C" int adsb_debug_tile_stamps(adsb_ctx *c, uint32_t *out, size_t max_til
     return ADSB_OK;
 }
 
-static uint32_t *grp1_of(adsb_ctx *c, uint32_t set) { return c->grp + (size_t)set * (c->n_grp1 + c->n_grp2); }
-static uint32_t *grp2_of(adsb_ctx *c, uint32_t set) { return grp1_of(c, set) + c->n_grp1; }
-
-static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t grp_set, uint32_t tile_first,
-                                   uint32_t tile_count, bool count_groups)
+static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t tile_first, uint32_t tile_count,
+                                   bool first_pass)
 {
     adsbk::DemodArgs a{};
     a.iq = c->last_iq;
@@ -310,7 +307,7 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.tiles_per_channel = c->last_tpc;
     a.tile_first = tile_first;
     a.tile_count = tile_count;
-    a.count_groups = count_groups ? 1u : 0u;
+    a.count_groups = first_pass ? 1u : 0u;
     a.offset_base = c->last_base;
     a.fused_pass_only = c->fused_pass_only ? 1u : 0u;
     a.seg = r.seg;
@@ -318,39 +315,33 @@ static adsbk::DemodArgs demod_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t
     a.pool_first = c->n_tiles_max * adsbk::kQuota;
     a.cap_slots = c->cap_slots;
     a.hdr = r.hdr;
-    a.hdr_pub = (count_groups && c->ext_blob) ? static_cast<uint64_t *>(c->ext_blob) : nullptr;
-    a.grp1 = grp1_of(c, grp_set);
-    a.grp2 = grp2_of(c, grp_set);
-    a.pool_off = (c->pool_off && count_groups) ? 1u : 0u; // (first passes only: the re-run of lost tiles needs the pool)
+    a.hdr_pub = (first_pass && c->ext_blob) ? static_cast<uint64_t *>(c->ext_blob) : nullptr;
+    a.pool_off = (c->pool_off && first_pass) ? 1u : 0u; // (first passes only: the re-run of lost tiles needs the pool)
     a.stamps = c->stamps;
     return a;
 }
 
-static adsbk::CompactArgs compact_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t grp_set, int zero_set,
-                                       uint32_t tile_first, uint32_t tile_count, bool rerun)
+// launch_epoch: the index of the launch the pass belongs to (tags the look-back words)
+static adsbk::FinishArgs finish_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32_t launch_epoch, uint32_t tile_first,
+                                     uint32_t tile_count, bool rerun)
 {
-    adsbk::CompactArgs a{};
+    adsbk::FinishArgs a{};
     a.seg = r.seg;
     a.slots = r.slots;
     a.out_start = rerun ? c->out_start : nullptr;
-    a.grp1 = grp1_of(c, grp_set);
-    a.grp2 = grp2_of(c, grp_set);
-    a.zero1 = zero_set >= 0 ? grp1_of(c, (uint32_t)zero_set) : nullptr;
-    a.zero2 = zero_set >= 0 ? grp2_of(c, (uint32_t)zero_set) : nullptr;
-    a.n_grp1 = c->n_grp1;
-    a.n_grp2 = c->n_grp2;
-    a.chan_counts = r.chan_counts;
+    a.lb = c->lb;
+    a.lb_groups_at = c->lb_groups_at;
+    a.chan_prefix = rerun ? nullptr : r.chan_prefix;
+    a.epoch = (launch_epoch + 1u) & 0x3FFFFFFFu;
     const bool ext = c->ext_blob && !rerun;
     a.out = ext ? reinterpret_cast<adsb_frame *>(static_cast<char *>(c->ext_blob) + 32) : r.out;
     a.hdr_pub = ext ? static_cast<uint64_t *>(c->ext_blob) : nullptr;
-    a.n_tiles = c->last_tiles;
     a.tiles_per_channel = c->last_tpc;
     a.n_channels = c->last_channels;
     a.max_out = ext ? (uint32_t)std::min<size_t>(c->ext_frames, c->cfg.max_out) : (uint32_t)c->cfg.max_out;
     if (rerun) { a.out = c->last_out; a.max_out = c->last_cap; }
     a.tile_first = tile_first;
     a.tile_count = tile_count;
-    a.write_header = rerun ? 0u : 1u;
     a.hdr = r.hdr;
     return a;
 }
@@ -377,9 +368,8 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->fields_current = false;
     c->trk_done = false;
 
-    // Launch i uses result set i&1 and counter set i%3; its ordering pass clears counter set
-    // (i+2)%3 for launch i+2.  The demod kernel only has to wait for the ordering pass of launch
-    // i-2 (same result set), so ordering pass i and demod kernel i+1 overlap.
+    // Launch i uses result set i & 1.  (ADSB_OVERLAP_ORDERING=1: the finishing kernel of launch i runs on `aux` beside
+    // the scan of launch i+1, which only has to wait for the finishing kernel of launch i-2: same result set.)
     const uint32_t i = c->launch_idx;
     adsb_ctx::ResultSet &r = c->rs[i & 1u];
     if (c->own_aux && r.g_pending) HIPCHK(hipStreamWaitEvent(c->stream, r.g_done, 0));
@@ -393,24 +383,21 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
         }
         ev = c->ev[c->ev_count % kTimingRing];
     }
-    const adsbk::DemodArgs da = demod_args(c, r, i % 3u, 0, c->last_tiles, true);
-    // (ADSB_OVERLAP_ORDERING=1: the two small kernels run beside the next launch's scan.  The event the other stream
-    // waits for rides on the scan's own dispatch packet: no barrier packet between two scans.)
+    const adsbk::DemodArgs da = demod_args(c, r, 0, c->last_tiles, true);
+    // (ADSB_OVERLAP_ORDERING=1: the event the other stream waits for rides on the scan's own dispatch packet: no
+    // barrier packet between two scans.)
     hipEvent_t scan_done = ev ? ev[1] : (c->own_aux ? r.k_done : nullptr);
     HIPCHK(adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, c->scan, da, ev ? ev[0] : nullptr, scan_done));
-    if (c->last_tiles == 0) {
-        // exactly 240 samples: zero offsets (adsb.rs:98 iterates 0..0).  No scan kernel runs, so nobody clears this
-        // result set's flag words (block 0 of the scan does): the ordering pass below only ORs bits in.
-        HIPCHK(hipMemsetAsync(&r.hdr->flags, 0, sizeof(uint32_t), c->stream));
-        if (c->ext_blob) HIPCHK(hipMemsetAsync(static_cast<char *>(c->ext_blob) + 16, 0, sizeof(uint64_t), c->stream));
+    if (c->own_aux && scan_done && c->last_tiles) HIPCHK(hipStreamWaitEvent(c->aux, scan_done, 0));
+    // second kernel: CRC-24 / repair of the survivors the scan kernel sliced, and the ordered list.  Without tiles
+    // (exactly 240 samples: adsb.rs:98 iterates 0..0) or in measurement mode (scan only) the list is empty.
+    if (c->last_tiles == 0 || c->fused_pass_only) {
+        adsbk::Header *hdr = r.hdr;
+        HIPCHK(adsbk::launch_empty_result(c->aux, hdr, c->ext_blob ? static_cast<uint64_t *>(c->ext_blob) : nullptr,
+                                          r.chan_prefix, c->last_channels, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr));
+    } else {
+        HIPCHK(adsbk::launch_finish(c->aux, finish_args(c, r, i, 0, c->last_tiles, false), ev ? ev[2] : nullptr, ev ? ev[3] : nullptr));
     }
-    // second kernel: slice + CRC of the survivors the scan kernel listed (the experimental streaming kernel decodes
-    // in place and marks its tiles decoded; measurement mode stops after the scan)
-    if (c->own_aux && scan_done) HIPCHK(hipStreamWaitEvent(c->aux, scan_done, 0));
-    if (!c->fused_pass_only)
-        HIPCHK(adsbk::launch_decode(c->aux, c->cfg.sample_type, c->mag_mode, da, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr));
-    HIPCHK(adsbk::launch_gather(c->aux, compact_args(c, r, i % 3u, (int)((i + 2u) % 3u), 0, c->last_tiles, false),
-                                ev ? ev[2] : nullptr, ev ? ev[3] : nullptr));
     // (same stream: in-order already; adsb_stream_wait_results records the event when somebody asks for it)
     if (c->own_aux) {
         HIPCHK(hipEventRecord(r.g_done, c->aux));
@@ -447,7 +434,6 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
     HIPCHK(hipStreamSynchronize(c->aux));
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t n = c->last_tiles;
-    const uint32_t grp_set = r.li.idx % 3u; // the launch's own counter set (not read on this path: positions are host-planned)
     std::vector<adsbk::Seg> seg(n);
     HIPCHK(hipMemcpyAsync(seg.data(), r.seg, sizeof(adsbk::Seg) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -471,10 +457,8 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
         hipError_t e;
         if ((e = hipMemsetAsync(&r.hdr->alloc, 0, sizeof(unsigned long long), c->stream)) != hipSuccess ||
             (e = adsbk::launch_demod(c->stream, c->cfg.sample_type, c->mag_mode, c->scan,
-                                     demod_args(c, r, grp_set, t0, t1 - t0, false))) != hipSuccess ||
-            (e = adsbk::launch_decode(c->stream, c->cfg.sample_type, c->mag_mode,
-                                      demod_args(c, r, grp_set, t0, t1 - t0, false))) != hipSuccess ||
-            (e = adsbk::launch_gather(c->stream, compact_args(c, r, grp_set, -1, t0, t1 - t0, true))) != hipSuccess)
+                                     demod_args(c, r, t0, t1 - t0, false))) != hipSuccess ||
+            (e = adsbk::launch_finish(c->stream, finish_args(c, r, r.li.idx, t0, t1 - t0, true))) != hipSuccess)
             rc = (int)e;
         t0 = t1;
     }
@@ -498,6 +482,7 @@ static int sync_header(adsb_ctx *c)
     adsb_ctx::ResultSet &r = c->rs[c->last];
     HIPCHK(hipMemcpyAsync(c->hdr_host, r.hdr, sizeof(adsbk::Header), hipMemcpyDeviceToHost, c->aux));
     HIPCHK(hipStreamSynchronize(c->aux)); // the ordering pass of the last launch ran on aux before this copy
+    if (c->hdr_host->retry & 4u) return ADSB_E_STATE; // finish_order gave up waiting for a workgroup (never seen; see its comment)
     if (c->hdr_host->retry) {
         int rc = rerun_in_batches(c, r);
         if (rc != ADSB_OK) return rc;
@@ -530,19 +515,15 @@ extern "C" int adsb_fetch(adsb_ctx *c, adsb_frame *out, size_t max_out, size_t *
     if (n > max_out) { n = max_out; fl |= ADSB_FLAG_TRUNCATED; }
     adsb_ctx::ResultSet &r = c->rs[c->last];
     if (n) HIPCHK(hipMemcpyAsync(out, c->last_out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, c->aux));
-    std::vector<uint64_t> cc;
+    std::vector<uint64_t> pre;
     if (per_channel_counts) {
-        HIPCHK(hipMemcpyAsync(per_channel_counts, r.chan_counts, sizeof(uint64_t) * c->last_channels,
-                              hipMemcpyDeviceToHost, c->aux));
+        pre.resize((size_t)c->last_channels + 1);
+        HIPCHK(hipMemcpyAsync(pre.data(), r.chan_prefix, sizeof(uint64_t) * pre.size(), hipMemcpyDeviceToHost, c->aux));
     }
     HIPCHK(hipStreamSynchronize(c->aux));
-    if (per_channel_counts && n < c->hdr_host->n_out) { // caller's array was the tighter cap
-        uint64_t left = n;
-        for (uint32_t k = 0; k < c->last_channels; ++k) {
-            uint64_t take = std::min(per_channel_counts[k], left);
-            per_channel_counts[k] = take;
-            left -= take;
-        }
+    if (per_channel_counts) { // frames of channel k in `out` = its share of the first n frames of the list
+        for (uint32_t k = 0; k < c->last_channels; ++k)
+            per_channel_counts[k] = std::min<uint64_t>(pre[k + 1], n) - std::min<uint64_t>(pre[k], n);
     }
     *n_out = (size_t)n;
     if (total_found) *total_found = c->hdr_host->total_found;
@@ -721,19 +702,19 @@ static int timing_read(adsb_ctx *c, double *demod_ms, double *order_ms, double *
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->aux));
     uint32_t n = std::min<uint32_t>(c->ev_count, kTimingRing);
-    double a = 0, b = 0, d = 0;
+    double a = 0, b = 0;
     for (uint32_t k = 0; k < n; ++k) {
-        float x = 0, y = 0, z = 0;
+        float x = 0, y = 0;
         HIPCHK(hipEventElapsedTime(&x, c->ev[k][0], c->ev[k][1]));
         HIPCHK(hipEventElapsedTime(&y, c->ev[k][2], c->ev[k][3]));
-        if (!c->fused_pass_only) HIPCHK(hipEventElapsedTime(&z, c->ev[k][4], c->ev[k][5]));
         a += x;
         b += y;
-        d += z;
     }
+    // a launch is two kernels since round 3: the scan and finish_order (CRC / repair + the ordered list in one); the
+    // latter is reported as the "decode" figure, the separate ordering pass no longer exists (0)
     if (demod_ms) *demod_ms = n ? a / n : 0.0;
-    if (order_ms) *order_ms = n ? b / n : 0.0;
-    if (decode_ms) *decode_ms = n ? d / n : 0.0;
+    if (decode_ms) *decode_ms = n ? b / n : 0.0;
+    if (order_ms) *order_ms = decode_ms ? 0.0 : (n ? b / n : 0.0);
     if (n_launches) *n_launches = n;
     c->ev_count = 0;
     return ADSB_OK;

@@ -51,15 +51,11 @@ constexpr uint32_t kNoBase = 0xFFFFFFFFu;
 // shared pool with one returning atomic.  (One atomic per tile on a single address measured as the
 // bottleneck: ~80 atomics/us per address vs 62 tiles/us.)
 constexpr uint32_t kQuota = 32;
-// Level-2 group counters are sharded 16 ways by the level-1 group index so that the ~1000 tiles in
-// flight at any time never pile onto one address.
-constexpr int kGrp2Shards = 16;
-
 // One entry per tile, written unconditionally by the demod kernel.
 struct Seg {
     uint32_t base;    // first temp slot of this tile, kNoBase if the slot store was full
     uint32_t cand;    // offsets that passed the preamble+DF17 gate (slots reserved; the scan kernel writes each survivor's offset there)
-    uint32_t valid;   // of those, frames that passed CRC / single-bit repair (written by the decode kernel)
+    uint32_t valid;   // of those, frames that passed CRC / single-bit repair (written by the finishing kernel)
     uint32_t decoded; // 1: `valid` is already final when the scan kernel ends (a tile without slots, counted in place)
 };
 
@@ -72,10 +68,6 @@ struct Header {
     unsigned long long alloc; // pool allocator for tiles over their quota (reset by the gather kernel)
 };
 
-// Tiles are grouped 64 x 64 so that any tile's position in the final list is a sum of at most
-// 3 x 64 counters (no separate scan kernel): grp1[t >> 6], grp2[t >> 12].
-constexpr int kGrpShift = 6;
-
 struct DemodArgs {
     const void *iq;            // channel 0, sample 0
     uint64_t n_samples;        // per channel
@@ -83,7 +75,7 @@ struct DemodArgs {
     uint32_t tiles_per_channel;
     uint32_t tile_first;       // global tile id of blockIdx.x == 0
     uint32_t tile_count;       // workgroups in this launch
-    uint32_t count_groups;     // 1: add Seg::valid into grp1/grp2; 0: re-run of known tiles
+    uint32_t count_groups;     // 1: first pass of a launch (clears the header's flags); 0: re-run of known tiles
     uint32_t fused_pass_only;  // measurement (adsb_debug_fused_pass_only): magnitude + gate only, survivors counted but not decoded
     uint64_t offset_base;      // added to every frame's offset (adsb_set_stream_base: position of sample 0 in a longer stream)
     Seg *seg;
@@ -92,26 +84,24 @@ struct DemodArgs {
     uint32_t cap_slots;        // pool capacity
     Header *hdr;
     uint64_t *hdr_pub;         // optional caller-owned header copy (adsb_set_result_target): its flags word is cleared here
-    uint32_t *grp1, *grp2;     // this launch's parity
     uint32_t pool_off;         // test knob (adsb_debug_pool_limit): 1 = the shared slot pool hands out nothing
     unsigned long long *stamps; // diagnostic builds (-DADSB_TILE_STAMPS=1) only: 64 bytes of cycle counters per tile
 };
 
-struct CompactArgs {
-    const Seg *seg;
-    const adsb_frame *slots;
-    const uint32_t *out_start; // optional [n_tiles]: host-planned positions (re-run path)
-    const uint32_t *grp1, *grp2;
-    uint32_t *zero1, *zero2;   // the other parity, cleared for the next launch (may be null)
-    uint32_t n_grp1, n_grp2;
-    uint64_t *chan_counts;     // [n_channels]
+// finish_order: CRC-24 / repair of the survivors + the ordered list, in one kernel (see adsb_kernels.hip)
+struct FinishArgs {
+    Seg *seg;
+    adsb_frame *slots;
     adsb_frame *out;
-    uint32_t n_tiles;
+    const uint32_t *out_start; // optional [n_tiles]: host-planned positions (re-run of lost tiles): no look-back, no header
+    uint64_t *lb;              // exchange words (value | flag | epoch), never cleared, tagged with `epoch`: one per
+    uint32_t lb_groups_at;     // workgroup from lb[0], one per 64 workgroups from lb[lb_groups_at]
+    uint64_t *chan_prefix;     // optional [n_channels + 1]: frames before each channel's first tile; [n_channels] = total
+    uint32_t epoch;            // launch index + 1 (30 bits)
     uint32_t tiles_per_channel;
     uint32_t n_channels;
     uint32_t max_out;
-    uint32_t tile_first, tile_count; // gather range
-    uint32_t write_header;
+    uint32_t tile_first, tile_count;
     Header *hdr;
     uint64_t *hdr_pub;         // optional caller-owned copy of {n_out, total_found, flags} (4 x u64)
 };
@@ -125,12 +115,13 @@ hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]
 // scan: kScanNsq / kScanRoot (i8 only; CS16 has one kernel)
 hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, const DemodArgs &a,
                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-// second kernel of a launch (finish_candidates): CRC-24 + single-bit repair + ordering inside a tile of the survivors
-// the scan kernel sliced into their slots (same DemodArgs)
-hipError_t launch_decode(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a,
-                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0 = nullptr,
-                         hipEvent_t e1 = nullptr);
+// second kernel of a launch (finish_order): CRC-24 + single-bit repair of the survivors the scan kernel sliced into
+// their slots, and the ordered frame list
+hipError_t launch_finish(hipStream_t s, const FinishArgs &a, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// the header of an empty list (no tiles, or a measurement launch without the finishing kernel)
+hipError_t launch_empty_result(hipStream_t s, Header *hdr, uint64_t *hdr_pub, uint64_t *chan_prefix, uint32_t n_channels,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+constexpr int kFinishTilesPerWg = 32;
 
 bool tile_stamps_built(); // -DADSB_TILE_STAMPS=1 diagnostic build: DemodArgs::stamps holds 64 bytes per tile
 

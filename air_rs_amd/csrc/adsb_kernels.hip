@@ -799,8 +799,6 @@ constexpr int kNsqFull = kNsqLog / (kThreads * 8);  // sweeps every lane takes p
 constexpr int kNsqTail = kNsqLog % (kThreads * 8);  // logical dwords of the last, partial sweep (the halo: 256)
 static_assert(kNsqIters - kNsqFull <= 1 && kNsqTail % 8 == 0, "at most one partial sweep of whole lanes");
 
-// sweeps [IT0, IT1) of a tile's loads
-template <int IT0 = 0, int IT1 = kNsqIters>
 __device__ __forceinline__ void nsq_issue_loads(const DemodArgs &p, const TilePos &tp, uint32_t tid,
                                                 u32x4 (&ra)[kNsqIters], u32x4 (&rb)[kNsqIters])
 {
@@ -808,12 +806,11 @@ __device__ __forceinline__ void nsq_issue_loads(const DemodArgs &p, const TilePo
     // (the sweep's constant goes into the SGPR offset, which the descriptor's bounds check covers:
     // tools/ubench/soffset_probe.hip; reads past the channel end return zeros)
 #pragma unroll
-    for (int it = IT0; it < (IT1 < kNsqFull ? IT1 : kNsqFull); ++it) {
+    for (int it = 0; it < kNsqFull; ++it) {
         ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16), ADSB_LOAD_AUX);
         rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16) + 2 * kNsqHalf, ADSB_LOAD_AUX);
     }
-    if (kNsqTail && IT0 <= kNsqFull && IT1 > kNsqFull &&
-        __builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kNsqTail) { // (whole waves past the halo skip it)
+    if (kNsqTail && __builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kNsqTail) { // (whole waves past the halo skip it)
         ra[kNsqFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kNsqFull * (kThreads * 16), ADSB_LOAD_AUX);
         rb[kNsqFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kNsqFull * (kThreads * 16) + 2 * kNsqHalf, ADSB_LOAD_AUX);
     }
@@ -911,15 +908,6 @@ __device__ __forceinline__ uint32_t nsq_root(uint32_t v) // floor(sqrt(v - 72)),
 #ifndef ADSB_NSQ_AHEAD
 #define ADSB_NSQ_AHEAD 12 // granules of four pairs resident ahead of the current block in the nsq gate (>= 8)
 #endif
-#ifndef ADSB_NSQ_TPW
-#define ADSB_NSQ_TPW 1
-#endif
-constexpr int kNsqTilesPerWg = ADSB_NSQ_TPW; // consecutive tiles per workgroup of the nsq scan (see demod_tiles)
-#ifndef ADSB_NSQ_EARLY
-#define ADSB_NSQ_EARLY 2
-#endif
-constexpr int kNsqEarly = ADSB_NSQ_EARLY;    // sweeps of the next tile whose loads are issued before the gate (TPW > 1)
-
 template <bool F16OK>
 __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *cand, uint16_t *list, uint32_t *count,
                                                const uint32_t tid, const uint32_t n_valid)
@@ -1016,22 +1004,19 @@ __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *ca
 // tile in ~10 % more VALU instructions (loop-carried registers, SGPR spills) and come out 7 % slower: in-kernel cycle
 // stamps (tools/gpu/tile_stamps.py) show the SIMDs VALU-saturated while any three of the four slots compute, so
 // filling the gaps buys nothing -- the instruction count is what bounds this kernel.
-// TPW (nsq only): consecutive tiles one workgroup takes, one after the other.  With TPW > 1 the loads of the next
-// tile are issued as soon as phase 1 has consumed the registers of the current one and stay in flight through its gate
-// and slice: the workgroup no longer waits a whole HBM round trip per tile, which at four waves per SIMD (the image
-// holds 2 bytes of LDS per sample) is what kept both the VALU and the memory pipe partly idle.
+// Waves per SIMD the register allocation is held to = workgroups per CU the LDS image allows (4 waves per workgroup):
+// 8 for the i8 root scan (u8 magnitudes: 19 KB), 4 for the 16-bit images (nsq, CS16: 35-38 KB).
 #ifndef ADSB_SCAN_WAVES
-#define ADSB_SCAN_WAVES 4 // waves per SIMD the register allocation is held to (the LDS image allows 4 workgroups per CU)
+#define ADSB_SCAN_WAVES 4
 #endif
-template <int ST, int MAGMODE, int SCAN, int TPW = 1>
-__global__ __launch_bounds__(kThreads, ADSB_SCAN_WAVES) void demod_tiles(DemodArgs p)
+template <int ST, int MAGMODE, int SCAN>
+__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoot) ? 8 : ADSB_SCAN_WAVES) void demod_tiles(DemodArgs p)
 {
     typedef Lds<ST, SCAN> L;
     typedef TileCfg<ST> TC; // tile length of this sample type
     typedef typename L::mag_t mag_t;
     constexpr bool NSQ = L::kNsq;
     static_assert(kThreads / 64 <= 4, "misc[4 + wave] must stay below misc[8]");
-    static_assert(TPW == 1 || NSQ, "several tiles per workgroup: nsq scan only");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
     mag_t *mag = reinterpret_cast<mag_t *>(smem);
@@ -1040,50 +1025,36 @@ __global__ __launch_bounds__(kThreads, ADSB_SCAN_WAVES) void demod_tiles(DemodAr
     uint16_t *list = reinterpret_cast<uint16_t *>(smem + L::kOffList);
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
 
-    const uint32_t tid0 = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
 
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
 #if ADSB_TILE_STAMPS
-    const uint32_t tid = tid0, wave = tid0 >> 6;
     unsigned long long ts_prev = 0;
     uint32_t ts_seg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     ts_seg[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     TSTAMP(-1);
     ts_seg[8] = (uint32_t)ts_prev; // s_memtime next to the s_memrealtime above: the shader clock under this load
 #endif
-    const uint32_t tile_first = p.tile_first + blockIdx.x * TPW;
-    const uint32_t tile_end = p.tile_first + p.tile_count;
-    // [phase:1 magnitude (loads, stores)]
-    // ---- phase 1, first half: the loads go out before anything else ------------------------------------------------
-    u32x4 raw[NSQ ? 1 : P1<ST>::kIters];
-    u32x4 raw_a[NSQ ? kNsqIters : 1], raw_b[NSQ ? kNsqIters : 1];
-    if constexpr (NSQ) nsq_issue_loads(p, tile_pos<TC::kTileT>(p, tile_first), tid0, raw_a, raw_b);
-    else issue_tile_loads<ST>(p, tile_pos<TC::kTileT>(p, tile_first), true, tid0, raw);
-    TSTAMP(0); // prologue, loads issued
-    if (tid0 == 0 && blockIdx.x == 0) {
-        p.hdr->retry = 0;
-        if (p.count_groups) { // first pass of a launch: the ordering pass ORs this launch's flags in
-            p.hdr->flags = 0;
-            if (p.hdr_pub) p.hdr_pub[2] = 0;
-        }
-    }
-#pragma unroll 1
-    for (int tk = 0; tk < TPW; ++tk) {
-        const uint32_t tile = tile_first + tk;
-        if (TPW > 1 && tile >= tile_end) break; // (workgroup-uniform)
-#if !ADSB_TILE_STAMPS
-        // With several tiles per workgroup everything derived from the thread index is loop-invariant; hipcc would
-        // hoist it all (addresses, lane constants of three phases) and keep it live through the whole tile: 128
-        // VGPRs and spills.  An opaque copy per iteration makes it recompute the few values where they are used.
-        uint32_t tid = tid0;
-        if constexpr (TPW > 1) asm volatile("" : "+v"(tid));
-        const uint32_t lane = tid & 63, wave = tid >> 6;
-#else
-        const uint32_t lane = tid & 63;
-#endif
+    {
+        const uint32_t tile = p.tile_first + blockIdx.x;
         const TilePos tp = tile_pos<TC::kTileT>(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
+        // [phase:1 magnitude (loads, stores)]
+        // ---- phase 1, first half: the loads go out before anything else --------------------------------------------
+        u32x4 raw[NSQ ? 1 : P1<ST>::kIters];
+        u32x4 raw_a[NSQ ? kNsqIters : 1], raw_b[NSQ ? kNsqIters : 1];
+        if constexpr (NSQ) nsq_issue_loads(p, tp, tid, raw_a, raw_b);
+        else issue_tile_loads<ST>(p, tp, true, tid, raw);
+        TSTAMP(0); // prologue, loads issued
+        if (tid == 0 && blockIdx.x == 0) {
+            p.hdr->retry = 0;
+            if (p.count_groups) { // first pass of a launch: the finishing kernel ORs this launch's flags in
+                p.hdr->flags = 0;
+                if (p.hdr_pub) p.hdr_pub[2] = 0;
+            }
+        }
         if (tid == 0) {
             misc[8] = 0;  // valid-frame counter
             misc[12] = 0; // survivor counter
@@ -1097,12 +1068,6 @@ __global__ __launch_bounds__(kThreads, ADSB_SCAN_WAVES) void demod_tiles(DemodAr
         if constexpr (NSQ) wave_big = nsq_image_to_lds(raw_a, raw_b, img, tid);
         else wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
         if ((NSQ || ST == ADSB_SAMPLE_I16) && lane == 0) misc[4 + wave] = wave_big ? 1u : 0u; // (every wave writes its own word)
-        // the next tile's samples: the first kNsqEarly sweeps are in flight through this tile's gate and slice, the
-        // rest -- the gate needs the registers -- from the end of the gate on
-        const bool more = TPW > 1 && tk + 1 < TPW && tile + 1 < tile_end; // (workgroup-uniform)
-        if constexpr (TPW > 1) {
-            if (more) nsq_issue_loads<0, kNsqEarly>(p, tile_pos<TC::kTileT>(p, tile + 1), tid, raw_a, raw_b);
-        }
         TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
         TSTAMP(2); // barrier
@@ -1132,9 +1097,6 @@ __global__ __launch_bounds__(kThreads, ADSB_SCAN_WAVES) void demod_tiles(DemodAr
         }
 #endif
         TSTAMP(3); // phase 2
-        if constexpr (TPW > 1) {
-            if (more) nsq_issue_loads<kNsqEarly, kNsqIters>(p, tile_pos<TC::kTileT>(p, tile + 1), tid, raw_a, raw_b);
-        }
         __syncthreads();
         TSTAMP(4); // barrier
 
@@ -1267,7 +1229,6 @@ __global__ __launch_bounds__(kThreads, ADSB_SCAN_WAVES) void demod_tiles(DemodAr
             e.decoded = base_slot == kNoBase ? 1u : 0u;
             p.seg[tile] = e; // (finish_candidates sums the groups' counters, this tile's count included)
         }
-        if constexpr (TPW > 1) __syncthreads(); // the image, the list and the counters are the next tile's from here on
     }
     // [phase:end]
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
@@ -1316,33 +1277,38 @@ constexpr SynSorted make_syn_sorted()
 }
 __constant__ SynSorted kSynSorted = make_syn_sorted();
 
-// finish_candidates: the second kernel of a launch.  The scan kernel (demod_tiles) left, per tile, `Seg{base, cand}` and,
-// in the slots base .. base+cand-1, every gate survivor's absolute offset and 14 sliced bytes (unordered when cand <=
-// kSparseCap, ascending otherwise).  One workgroup of 16 waves takes 32 consecutive tiles (half a GROUP of 64, the unit
-// of the gather pass's first-level counters), two tiles per wave, one LANE per survivor: the lane loads its 24-byte record,
-// runs the byte-wise CRC-24 over the 11 data bytes (1 KB table in LDS), compares with the received CRC; a non-zero
-// syndrome is looked up among the 88 data-bit syndromes (sorted, binary search) and that bit flipped (crc.rs:49-65: a
-// flip in the CRC field itself never matches); the lane's rank among the tile's survivors by offset (a readlane loop:
-// <= 64 per tile unless the tile is dense, and then they are already in order) is where the finished record {offset,
-// bytes, status, fixed_bit} goes, so that the gather pass finds every tile's slots in offset order.  The tile's
-// valid-frame count goes to its Seg; the workgroup sums its tiles in LDS and adds the sum to the group's first- and
-// second-level counters with ONE atomic each (2 and 8 arrivals per address).  Per-tile atomics, as the in-tile
-// decoder used to issue them spread over the whole scan, cost 70 us here, where 16 384 of them arrive within a few
-// microseconds on 320 addresses (measured: 0.085 ms with, 0.013 ms without them).
-// All loads of a wave's tiles are issued before the first is used (two memory round trips per wave), and the tiles are
-// processed together in straight-line code: the kernel is a chain of dependent LDS lookups (11 for the CRC, 7 for
-// the search) and a readlane loop per tile, and interleaving two or four of them is what its time depends on
-// (14.8 us one tile after the other with 64-bit rank compares, 12.2 us interleaved, 11.5 us with two tiles per wave).
-#ifndef ADSB_FINISH_TPW
-#define ADSB_FINISH_TPW 2 // (measured after the chains were interleaved: 1 024 threads x 2 tiles 11.5 us, x 4 12.2, 512 x 8 14.8)
-#endif
-#ifndef ADSB_FINISH_WAVES
-#define ADSB_FINISH_WAVES 16
-#endif
-constexpr int kFinishWaves = ADSB_FINISH_WAVES; // waves per workgroup
-constexpr int kFinishTPW = ADSB_FINISH_TPW;  // tiles per wave
-constexpr int kFinishTiles = kFinishWaves * kFinishTPW; // tiles per workgroup: a first-level group (64) or a power-of-two part of one
-static_assert(kFinishTiles <= (1 << kGrpShift) && ((1 << kGrpShift) % kFinishTiles) == 0, "a workgroup stays inside one first-level group");
+// finish_order: the second (and last) kernel of a launch.  The scan kernel (demod_tiles) left, per tile, `Seg{base,
+// cand}` and, in the slots base .. base+cand-1, every gate survivor's absolute offset and 14 sliced bytes (unordered when
+// cand <= kSparseCap, ascending otherwise).  This kernel checks them (CRC-24 over the 11 data bytes, byte-wise with a
+// 1 KB table in LDS; a non-zero syndrome is looked up among the 88 data-bit syndromes and that bit flipped, crc.rs:49-65:
+// a flip in the CRC field itself never matches) AND puts the valid frames into the final list in ascending (channel,
+// offset) order -- the order the reference's mpsc channel delivers them in (adsb.rs:98-111).  Rounds 1-2 did this in two
+// kernels (finish_candidates + gather_tiles: 16.5 + 5.9 us at 32 768 tiles, plus a dispatch gap); fused, every record is
+// read once, finished in registers and written once, to its final place:
+//   * one workgroup (4 waves) takes 32 consecutive tiles; a wave takes 4 tiles per pass, 16 lanes each, ONE LANE per
+//     survivor (a tile has ~8 survivors; tiles with more than 16 take the whole wave afterwards);
+//   * the lane's place inside its tile = its rank by offset among the tile's valid frames (15 DPP row rotations);
+//   * the tile's place in the list = valid frames in all earlier tiles.  Counts are reduced per workgroup; every
+//     workgroup publishes its aggregate in one 8-byte word {value | flag | epoch of the launch} (never cleared: a word
+//     of another epoch reads as "not there yet"), the last workgroup of every 64 also publishes the sum of its 64, and
+//     a workgroup's start is the sum of the (at most 63) aggregates before it in its own 64 plus the sums of all earlier
+//     64s: two dependent round trips of wave-wide loads, whatever the grid size; up to 1024 workgroups (1 GiB of i8 IQ)
+//     every workgroup simply sums all aggregates before it, one round trip (a chained look-back degenerates here:
+//     all workgroups reach it at the same moment, and the last one would walk N/64 windows one after the other; a
+//     ticket counter for arrival order costs 12 us by itself at 88 tickets per microsecond on one address);
+//   * a workgroup only ever waits for workgroups with a LOWER block index, and the lowest unfinished block is always
+//     resident (each XCD's dispatcher walks its share of the grid in order), so the waits end; a lane that still
+//     finds nothing after ~0.1 s gives up and reports it (Header::retry bit 2 -> ADSB_E_STATE on the host) instead of
+//     hanging the device;
+//   * the last workgroup knows the total: it writes the header and re-arms the pool.
+// A re-run of lost tiles (slot-pool overflow, host-planned positions in `out_start`) uses the same kernel without the
+// exchange.
+constexpr int kFinTiles = 32;          // tiles per workgroup
+constexpr int kFinThreads = 256;
+constexpr int kFinFan = 64;            // workgroups per second-level sum
+constexpr int kFinFlat = 1024;         // up to this many workgroups exchange their aggregates in one level
+constexpr uint32_t kLbReady = 1u;      // exchange word: value[31:0] | flag[33:32] | epoch[63:34]
+constexpr uint32_t kLbSpinLimit = 1u << 21; // polls (with s_sleep) before a lane gives up: ~0.1 s
 
 // CRC-24 + single-bit repair of one record per lane (w = the record as loaded; straight-line code, no branches, so
 // that the chains of a wave's four tiles interleave): returns whether the frame is valid; w comes back finished
@@ -1378,146 +1344,326 @@ __device__ __forceinline__ bool finish_record(uint32_t (&w)[6], const bool have,
     return valid;
 }
 
-// A later chunk (<= 64 survivors, one per lane) of a dense tile (more than 64 survivors: pathological input; the scan
-// kernel left them in offset order).  Returns the number of valid frames of the chunk (wave-uniform).
-__device__ __forceinline__ uint32_t finish_chunk(const DemodArgs &p, const Seg &e, uint32_t chunk, uint32_t ncl,
-                                                 uint32_t (&w)[6], const uint32_t *crc_tab, const uint32_t *syn_sorted,
-                                                 uint32_t lane)
+
+template <int N> __device__ __forceinline__ uint32_t row_ror(uint32_t v)
 {
-    const bool have = lane < ncl;
-    const bool valid = finish_record(w, have, crc_tab, syn_sorted);
-    if (have) {
-        uint2 *dst = reinterpret_cast<uint2 *>(p.slots + (size_t)e.base + chunk + lane);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dst[k] = make_uint2(w[2 * k], w[2 * k + 1]);
-    }
-    return (uint32_t)__builtin_popcountll(__ballot(valid));
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N /* row_ror:N */, 0xF, 0xF, true);
+}
+// number of lanes of this lane's 16-lane row whose key is smaller than its own (keys of lanes that do not count are
+// >= 0x10000, above every key that does)
+__device__ __forceinline__ uint32_t row_rank(uint32_t key)
+{
+    uint32_t below = 0;
+#define ADSB_RANK_STEP(N) below += row_ror<N>(key) < key ? 1u : 0u;
+    ADSB_RANK_STEP(1) ADSB_RANK_STEP(2) ADSB_RANK_STEP(3) ADSB_RANK_STEP(4) ADSB_RANK_STEP(5)
+    ADSB_RANK_STEP(6) ADSB_RANK_STEP(7) ADSB_RANK_STEP(8) ADSB_RANK_STEP(9) ADSB_RANK_STEP(10)
+    ADSB_RANK_STEP(11) ADSB_RANK_STEP(12) ADSB_RANK_STEP(13) ADSB_RANK_STEP(14) ADSB_RANK_STEP(15)
+#undef ADSB_RANK_STEP
+    return below;
 }
 
-__global__ __launch_bounds__(kFinishWaves * 64) void finish_candidates(DemodArgs p)
+__device__ __forceinline__ void store_record(adsb_frame *dst, const uint32_t (&w)[6])
 {
+    uint2 *d = reinterpret_cast<uint2 *>(dst);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = make_uint2(w[2 * k], w[2 * k + 1]);
+}
+__device__ __forceinline__ void load_record(const adsb_frame *src, uint32_t (&w)[6])
+{
+    const uint2 *s2 = reinterpret_cast<const uint2 *>(src);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint2 v = s2[k];
+        w[2 * k] = v.x;
+        w[2 * k + 1] = v.y;
+    }
+}
+
+// A tile with more than 16 survivors, by a whole wave: finished records go back to the tile's slots in offset order
+// (ranked when they arrived unordered, i.e. cand <= kSparseCap; more arrive in order); returns its valid count.
+__device__ __forceinline__ uint32_t finish_big_tile(const FinishArgs &a, const Seg &e, const uint32_t *crc_tab,
+                                                    const uint32_t *syn_sorted, uint32_t lane)
+{
+    uint32_t n_good = 0;
+    for (uint32_t chunk = 0; chunk < e.cand; chunk += 64) {
+        const uint32_t nc = (e.cand - chunk) < 64u ? (e.cand - chunk) : 64u;
+        uint32_t w[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
+        if (lane < nc) load_record(a.slots + (size_t)e.base + chunk + lane, w);
+        const bool valid = finish_record(w, lane < nc, crc_tab, syn_sorted);
+        uint32_t slot = lane;
+        if (e.cand <= (uint32_t)kSparseCap) { // one chunk, unordered: rank by offset (wrap-safe: a tile spans < 2^15)
+            const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[0]);
+            const int32_t mine = (int32_t)(w[0] - ref);
+            uint32_t below = 0;
+            for (uint32_t k = 0; k < nc; ++k) {
+                const int32_t other = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)w[0], (int)k) - ref);
+                below += other < mine ? 1u : 0u;
+            }
+            slot = below;
+        }
+        if (lane < nc) store_record(a.slots + (size_t)e.base + chunk + slot, w);
+        n_good += (uint32_t)__builtin_popcountll(__ballot(valid));
+    }
+    return n_good;
+}
+
+#ifndef ADSB_FIN_ABL
+#define ADSB_FIN_ABL 0 // measurement only (wrong results): 1 no exchange, 2 no CRC / search, 3 no stores of the list, 4 empty kernel
+#endif
+__global__ __launch_bounds__(kFinThreads) void finish_order(FinishArgs a)
+{
+#if ADSB_FIN_ABL == 4
+    if (a.max_out != 0xFFFFFFF1u) return;
+#endif
     __shared__ uint32_t crc_tab[256];
     __shared__ uint32_t syn_sorted[128];
-    __shared__ uint32_t counts[64];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t i = threadIdx.x; i < 256 + 128 + 64; i += kFinishWaves * 64) {
+    __shared__ uint32_t counts[kFinTiles]; // valid frames per tile of this workgroup
+    __shared__ uint32_t tpos[kFinTiles];   // position of each tile's first frame in the final list
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, sub = lane & 15;
+    const uint32_t blk = blockIdx.x, n_blk = gridDim.x;
+    const uint32_t tile0 = a.tile_first + blk * kFinTiles, t_end = a.tile_first + a.tile_count;
+
+    // ---- this wave's 8 tiles, 4 per pass: one lane per survivor ------------------------------------------------------
+    // One memory round trip for everything the lane needs: the tile's Seg AND, without waiting for it, the record at
+    // the place a small tile's survivor `sub` is known to be (a tile with at most kQuota survivors keeps them in its
+    // own fixed slots, tile * kQuota + i: demod_tiles), next to the tables' words.
+    Seg e[2];
+    uint32_t w[2][6], rank[2];
+    bool valid[2], small_[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint32_t idx = wave * 8 + p * 4 + g, tile = tile0 + idx;
+        e[p].base = kNoBase; e[p].cand = 0; e[p].valid = 0; e[p].decoded = 1;
+        w[p][0] = w[p][1] = 0xFFFFFFFFu;
+        w[p][2] = w[p][3] = w[p][4] = w[p][5] = 0;
+        if (tile < t_end) {
+            e[p] = a.seg[tile];
+            load_record(a.slots + (size_t)tile * kQuota + sub, w[p]);
+        }
+    }
+    for (uint32_t i = tid; i < 256 + 128; i += kFinThreads) {
         if (i < 256) crc_tab[i] = kCrcTab.v[i];
-        else if (i < 384) syn_sorted[i - 256] = kSynSorted.v[i - 256];
-        else counts[i - 384] = 0;
+        else syn_sorted[i - 256] = kSynSorted.v[i - 256];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const bool live = e[p].cand != 0 && e[p].base != kNoBase && !e[p].decoded;
+        small_[p] = live && e[p].cand <= 16u; // (then base == tile * kQuota: what was loaded above is its record)
+        if (!(small_[p] && sub < e[p].cand)) {
+            w[p][0] = w[p][1] = 0xFFFFFFFFu;
+            w[p][2] = w[p][3] = w[p][4] = w[p][5] = 0;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint32_t idx = wave * 8 + p * 4 + g;
+#if ADSB_FIN_ABL == 2
+        valid[p] = small_[p] && sub < e[p].cand && (w[p][2] & 1u) == 0;
+#else
+        valid[p] = finish_record(w[p], small_[p] && sub < e[p].cand, crc_tab, syn_sorted);
+#endif
+        // place inside the tile: rank by offset among the valid frames of the 16-lane row.  A tile's offsets lie within
+        // 2^15 of each other: relative to the row's first survivor they fit 16 bits (wrap-safe); bit 16 = does not count.
+        const uint32_t ref = (uint32_t)__shfl((int)w[p][0], (int)(lane & 48u), 64);
+        const uint32_t key = valid[p] ? ((w[p][0] - ref + 0x8000u) & 0xFFFFu) : 0x10000u;
+        rank[p] = row_rank(key);
+        const uint32_t cnt = (uint32_t)__builtin_popcount((uint32_t)(__ballot(valid[p]) >> (16u * g)) & 0xFFFFu);
+        if (sub == 0) counts[idx] = small_[p] ? cnt : (e[p].decoded ? e[p].valid : 0u); // (a tile the scan had to count itself keeps its count)
+    }
+    // tiles with more than 16 survivors (coarse or constant input): the whole wave, one tile after the other.  Which
+    // ones: a 2 x 4-bit mask from the Seg entries the rows already hold (no further loads on the usual path)
+    uint32_t big_mask = 0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const bool big = e[p].cand > 16u && e[p].base != kNoBase && !e[p].decoded;
+        const unsigned long long m = __ballot(big && sub == 0); // bits 0, 16, 32, 48: rows 0..3
+        big_mask |= (uint32_t)(((m >> 0) & 1u) | ((m >> 15) & 2u) | ((m >> 30) & 4u) | ((m >> 45) & 8u)) << (4 * p);
+    }
+    for (uint32_t left = big_mask; left; left &= left - 1) { // (wave-uniform)
+        const uint32_t i = (uint32_t)__builtin_ctz(left), idx = wave * 8 + i;
+        const Seg eb = a.seg[tile0 + idx];
+        const uint32_t n_good = finish_big_tile(a, eb, crc_tab, syn_sorted, lane);
+        if (lane == 0) counts[idx] = n_good;
     }
     __syncthreads();
 
-    const uint32_t tile0 = (p.tile_first / kFinishTiles + blockIdx.x) * kFinishTiles; // this workgroup's first tile
-    const uint32_t group = tile0 >> kGrpShift;
-    const uint32_t t_end = p.tile_first + p.tile_count;
-    // ---- both memory round trips of this wave's tiles up front ---------------------------------------------------
-    Seg e[kFinishTPW];
-    bool live[kFinishTPW];
+    // ---- where this workgroup's frames start: prefix inside the workgroup + look-back over the earlier ones ----------
+    if (wave == 0) {
+        const uint32_t c = lane < (uint32_t)kFinTiles ? counts[lane] : 0u;
+        uint32_t incl = c;
 #pragma unroll
-    for (int i = 0; i < kFinishTPW; ++i) {
-        const uint32_t tile = tile0 + wave * kFinishTPW + i;
-        const bool in_range = tile >= p.tile_first && tile < t_end; // (wave-uniform)
-        e[i].base = kNoBase; e[i].cand = 0; e[i].valid = 0; e[i].decoded = 1;
-        if (in_range) e[i] = p.seg[tile];
-        live[i] = in_range && e[i].cand != 0 && e[i].base != kNoBase && !e[i].decoded;
-    }
-    uint32_t w[kFinishTPW][6];
-#pragma unroll
-    for (int i = 0; i < kFinishTPW; ++i) {
-        w[i][0] = w[i][1] = 0xFFFFFFFFu;
-        w[i][2] = w[i][3] = w[i][4] = w[i][5] = 0;
-        if (live[i] && lane < e[i].cand) { // (first chunk; every record of a chunk is read before any is written)
-            const uint2 *src = reinterpret_cast<const uint2 *>(p.slots + (size_t)e[i].base + lane);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint2 v = src[k];
-                w[i][2 * k] = v.x;
-                w[i][2 * k + 1] = v.y;
-            }
+        for (int d = 1; d < kFinTiles; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += t;
         }
-    }
-    // ---- first chunk of all of this wave's tiles together: no branch on a tile's state, so the four CRC / search
-    // chains (dependent LDS lookups) and the four rank loops interleave instead of running one after the other ------
-    uint32_t ncl[kFinishTPW];
-    bool valid[kFinishTPW];
-#pragma unroll
-    for (int i = 0; i < kFinishTPW; ++i) {
-        ncl[i] = live[i] ? (e[i].cand < 64u ? e[i].cand : 64u) : 0u;
-        valid[i] = finish_record(w[i], lane < ncl[i], crc_tab, syn_sorted);
-    }
-    // where a record goes: its rank by offset among the tile's survivors (<= kSparseCap = 64 of them arrive unordered;
-    // more than that arrive in order).  A tile's offsets lie within 2^15 of each other: the low words relative to
-    // lane 0's order them (wrap-safe); one v_readlane + compare + add per survivor and tile.
-    uint32_t ref[kFinishTPW], below[kFinishTPW], nrank[kFinishTPW], kmax = 0;
-    int32_t mine[kFinishTPW];
-#pragma unroll
-    for (int i = 0; i < kFinishTPW; ++i) {
-        ref[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i][0]);
-        mine[i] = (int32_t)(w[i][0] - ref[i]);
-        below[i] = 0;
-        nrank[i] = (live[i] && e[i].cand <= (uint32_t)kSparseCap) ? ncl[i] : 0u;
-        kmax = nrank[i] > kmax ? nrank[i] : kmax;
-    }
-    for (uint32_t k = 0; k < kmax; ++k) {
-#pragma unroll
-        for (int i = 0; i < kFinishTPW; ++i) {
-            const int32_t other = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)w[i][0], (int)k) - ref[i]);
-            below[i] += (k < nrank[i] && other < mine[i]) ? 1u : 0u;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < kFinishTPW; ++i) {
-        const uint32_t tile = tile0 + wave * kFinishTPW + i;
-        const uint32_t slot = nrank[i] ? below[i] : lane;
-        if (lane < ncl[i]) {
-            uint2 *dst = reinterpret_cast<uint2 *>(p.slots + (size_t)e[i].base + slot);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dst[k] = make_uint2(w[i][2 * k], w[i][2 * k + 1]);
-        }
-        uint32_t n_good = live[i] ? (uint32_t)__builtin_popcountll(__ballot(valid[i])) : e[i].valid; // (a tile the scan kernel had to decode itself keeps its count)
-        if (live[i]) {
-            for (uint32_t chunk = 64; chunk < e[i].cand; chunk += 64) { // dense tile (pathological input): in order already
-                const uint32_t nc = (e[i].cand - chunk) < 64u ? (e[i].cand - chunk) : 64u;
-                uint32_t x[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
-                if (lane < nc) {
-                    const uint2 *src = reinterpret_cast<const uint2 *>(p.slots + (size_t)e[i].base + chunk + lane);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const uint2 v = src[k];
-                        x[2 * k] = v.x;
-                        x[2 * k + 1] = v.y;
+        const uint32_t total = __shfl(incl, kFinTiles - 1, 64);
+        unsigned long long before = 0; // valid frames in all earlier workgroups
+        if (a.out_start == nullptr && ADSB_FIN_ABL != 1) {
+            const unsigned long long tag = ((unsigned long long)a.epoch << 34) | ((unsigned long long)kLbReady << 32);
+            uint64_t *lb_a = a.lb, *lb_s = a.lb + a.lb_groups_at; // one word per workgroup | one per 64 workgroups
+            if (lane == 0) __hip_atomic_store(lb_a + blk, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t grp = blk / kFinFan, r = blk % kFinFan;
+            bool failed = false;
+            // polls `word` (where `want`) until it carries this launch's tag; all lanes leave together
+            auto wait_word = [&](const uint64_t *word, const bool want) -> unsigned long long {
+                unsigned long long v = 0;
+                bool ready = !want;
+                uint32_t spins = 0;
+                while (!__all(ready)) {
+                    if (!ready) {
+                        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = (v >> 32) == (tag >> 32);
+                        if (!ready) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > kLbSpinLimit) { failed = true; ready = true; v = 0; }
+                        }
                     }
                 }
-                n_good += finish_chunk(p, e[i], chunk, nc, x, crc_tab, syn_sorted, lane);
+                return want ? (v & 0xFFFFFFFFull) : 0ull;
+            };
+            auto wave_sum = [&](unsigned long long x) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint32_t lo = __shfl_xor((uint32_t)x, d, 64), hi32 = __shfl_xor((uint32_t)(x >> 32), d, 64);
+                    x += ((unsigned long long)hi32 << 32) | lo;
+                }
+                return x;
+            };
+            if (n_blk <= (uint32_t)kFinFlat) {
+                // small grids (up to 1024 workgroups = 1 GiB of i8 IQ): one level -- every aggregate before this one, 16
+                // independent loads per lane in flight at once, re-read until all carry the tag: ONE exchange round trip
+                unsigned long long acc;
+                uint32_t spins = 0;
+                bool ok;
+                do {
+                    unsigned long long v[kFinFlat / 64];
+#pragma unroll
+                    for (int u = 0; u < kFinFlat / 64; ++u) {
+                        const uint32_t k = (uint32_t)u * 64u + lane;
+                        v[u] = k < blk ? __hip_atomic_load(lb_a + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                    }
+                    acc = 0;
+                    ok = true;
+#pragma unroll
+                    for (int u = 0; u < kFinFlat / 64; ++u) {
+                        ok = ok && (v[u] >> 32) == (tag >> 32);
+                        acc += v[u] & 0xFFFFFFFFull;
+                    }
+                    if (!__all(ok)) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > kLbSpinLimit) { failed = true; ok = true; acc = 0; }
+                    }
+                } while (!__all(ok));
+                before = wave_sum(acc);
+            } else {
+                // the aggregates before this one inside its 64: one per lane
+                const unsigned long long in_grp = wave_sum(wait_word(lb_a + (size_t)grp * kFinFan + lane, lane < r));
+                if (r == kFinFan - 1 && lane == 0) { // the last of its 64 publishes their sum (a 64's frames fit 32 bits)
+                    const unsigned long long sum64 = in_grp + total;
+                    __hip_atomic_store(lb_s + grp, tag | (sum64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : sum64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // the sums of the earlier 64s: lane l takes l, l + 64, ... (their last workgroups have lower indices than this one)
+                unsigned long long earlier = 0;
+                for (uint32_t k0 = 0; k0 < grp; k0 += 64) earlier += wait_word(lb_s + k0 + lane, k0 + lane < grp); // (wave-uniform trip count)
+                before = in_grp + wave_sum(earlier);
             }
-            if (lane == 0) p.seg[tile].valid = n_good;
+            if (__any(failed) && lane == 0) atomicOr(&a.hdr->retry, 4u); // gave up waiting: the host returns ADSB_E_STATE
+            if (blk == n_blk - 1 && lane == 0) { // the last workgroup: the whole launch's total is known here
+                const unsigned long long tot = before + total, n_out = tot < a.max_out ? tot : a.max_out;
+                a.hdr->total_found = tot;
+                a.hdr->n_out = n_out;
+                // flags were cleared by the scan kernel; bits are OR-ed in (another workgroup may add INCOMPLETE)
+                if (tot > a.max_out) atomicOr(&a.hdr->flags, ADSB_FLAG_TRUNCATED);
+                a.hdr->alloc = 0; // pool allocator: ready for the next launch
+                if (a.hdr_pub) {
+                    a.hdr_pub[0] = n_out;
+                    a.hdr_pub[1] = tot;
+                    if (tot > a.max_out) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_TRUNCATED);
+                    a.hdr_pub[3] = 0;
+                }
+                if (a.chan_prefix) a.chan_prefix[a.n_channels] = tot;
+            }
         }
-        if (lane == 0) counts[wave * kFinishTPW + i] = n_good;
+        if (lane < (uint32_t)kFinTiles) {
+            const uint32_t tile = tile0 + lane;
+            unsigned long long pos = before + (incl - c);
+            if (a.out_start) pos = tile < t_end ? a.out_start[tile] : 0xFFFFFFFFu;
+            const uint32_t p32 = pos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)pos;
+            tpos[lane] = p32;
+            if (tile < t_end) {
+                // frames before each channel's first tile (adsb_fetch turns them into per-channel counts)
+                if (a.chan_prefix && tile % a.tiles_per_channel == 0) a.chan_prefix[tile / a.tiles_per_channel] = pos;
+            }
+        }
     }
     __syncthreads();
-    if (wave == 0 && p.count_groups) { // the group's counters: one add per workgroup (<= 64 / kFinishTiles arrivals per address)
-        uint32_t v = counts[lane];
+
+    // ---- every frame to its place -------------------------------------------------------------------------------------
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-        if (lane == 0 && v) {
-            atomicAdd(&p.grp1[group], v); // (zeroed by the ordering pass two launches ago)
-            atomicAdd(&p.grp2[(group >> kGrpShift) * kGrp2Shards + (group & (kGrp2Shards - 1))], v);
+    for (int p = 0; p < 2; ++p) {
+        const uint32_t idx = wave * 8 + p * 4 + g, tile = tile0 + idx;
+        const uint32_t dst = tpos[idx] + rank[p];
+        if (valid[p] && dst < a.max_out && tpos[idx] != 0xFFFFFFFFu && ADSB_FIN_ABL != 3) store_record(a.out + dst, w[p]);
+        if (sub == 0 && tile < t_end) {
+            if (small_[p]) a.seg[tile].valid = counts[idx];
+            // a tile that lost its slots (the pool was full) but whose frames are wanted: the host re-plans
+            if (e[p].base == kNoBase && e[p].cand != 0 && counts[idx] != 0 && tpos[idx] < a.max_out && a.out_start == nullptr) {
+                atomicOr(&a.hdr->retry, 1u);
+                atomicOr(&a.hdr->flags, ADSB_FLAG_INCOMPLETE); // visible to device-side consumers: the list has holes
+                if (a.hdr_pub) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_INCOMPLETE);
+            }
+        }
+    }
+    for (uint32_t left = big_mask; left; left &= left - 1) { // the big tiles' valid frames, from their slots (offset order), by the whole wave
+        const uint32_t i = (uint32_t)__builtin_ctz(left), idx = wave * 8 + i, tile = tile0 + idx;
+        const Seg eb = a.seg[tile];
+        if (lane == 0) a.seg[tile].valid = counts[idx];
+        uint32_t pos = tpos[idx];
+        if (pos >= a.max_out) continue;
+        for (uint32_t i0 = 0; i0 < eb.cand; i0 += 64) {
+            const uint32_t k = i0 + lane;
+            uint32_t x[6] = {0, 0, 0, 0, 0, 0xFF0000u};
+            if (k < eb.cand) load_record(a.slots + (size_t)eb.base + k, x);
+            const bool ok = k < eb.cand && ((x[5] >> 16) & 0xFFu) != 0xFFu;
+            const unsigned long long m = __ballot(ok);
+            const uint32_t dst = pos + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (ok && dst < a.max_out) store_record(a.out + dst, x);
+            pos += (uint32_t)__builtin_popcountll(m);
         }
     }
 }
 
-hipError_t launch_decode(hipStream_t s, int sample_type, int mag_mode, const DemodArgs &a, hipEvent_t e0, hipEvent_t e1)
+hipError_t launch_finish(hipStream_t s, const FinishArgs &a, hipEvent_t e0, hipEvent_t e1)
 {
-    (void)mag_mode;
-    (void)sample_type;
-    if (a.tile_count == 0) return hipSuccess;
-    const uint32_t g0 = a.tile_first / kFinishTiles, g1 = (a.tile_first + a.tile_count - 1) / kFinishTiles;
-    hipExtLaunchKernelGGL(finish_candidates, dim3(g1 - g0 + 1), dim3(kFinishWaves * 64), 0, s, e0, e1, 0, a);
+    const uint32_t blocks = (a.tile_count + kFinTiles - 1) / kFinTiles;
+    if (blocks == 0) return hipSuccess;
+    hipExtLaunchKernelGGL(finish_order, dim3(blocks), dim3(kFinThreads), 0, s, e0, e1, 0, a);
     return hipGetLastError();
 }
 
-// Timing events ride on the dispatch itself (hipExtLaunchKernelGGL): no extra barrier packets in
-// the stream, so the timed loop of bench.py is the same command stream as an untimed one.
+// No tiles at all (a 240-sample buffer: adsb.rs:98 iterates 0..0), or a measurement launch without the finishing
+// kernel: the header of an empty list.
+__global__ void empty_result_kernel(Header *hdr, uint64_t *hdr_pub, uint64_t *chan_prefix, uint32_t n_channels)
+{
+    if (threadIdx.x == 0) {
+        hdr->n_out = 0;
+        hdr->total_found = 0;
+        hdr->flags = 0;
+        hdr->retry = 0;
+        hdr->alloc = 0;
+        if (hdr_pub) { hdr_pub[0] = 0; hdr_pub[1] = 0; hdr_pub[2] = 0; hdr_pub[3] = 0; }
+    }
+    if (chan_prefix)
+        for (uint32_t k = threadIdx.x; k <= n_channels; k += blockDim.x) chan_prefix[k] = 0;
+}
+hipError_t launch_empty_result(hipStream_t s, Header *hdr, uint64_t *hdr_pub, uint64_t *chan_prefix, uint32_t n_channels,
+                               hipEvent_t e0, hipEvent_t e1)
+{
+    hipExtLaunchKernelGGL(empty_result_kernel, dim3(1), dim3(64), 0, s, e0, e1, 0, hdr, hdr_pub, chan_prefix, n_channels);
+    return hipGetLastError();
+}
+
 template <int ST>
 static hipError_t launch_demod_st(hipStream_t s, int mag_mode, const DemodArgs &a, uint32_t grid_x,
                                   hipEvent_t e0, hipEvent_t e1)
@@ -1539,175 +1685,11 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
 {
     if (a.tile_count == 0) return hipSuccess;
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
-        hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq, kNsqTilesPerWg>),
-                              dim3((a.tile_count + kNsqTilesPerWg - 1) / kNsqTilesPerWg), dim3(kThreads), 0, s, e0, e1, 0, a);
+        hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq>), dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);
     return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count, e0, e1);
-}
-
-// ---- ordering pass ---------------------------------------------------------------------------
-// Position of tile t's first frame in the final list = number of valid frames in tiles < t
-// (global tile order = channel-major, then ascending offset).  Wave-cooperative: every lane gets
-// the result.  Saturates at 2^32-1 (such positions are beyond any max_out).
-__device__ __forceinline__ uint32_t tile_prefix(const CompactArgs &a, uint32_t t, uint32_t lane)
-{
-    const uint32_t g = t >> kGrpShift, sg = t >> (2 * kGrpShift);
-    unsigned long long sum = 0;
-    for (uint32_t k = lane; k < sg * kGrp2Shards; k += 64) sum += a.grp2[k];
-    { const uint32_t k = (sg << kGrpShift) + lane; if (k < g) sum += a.grp1[k]; }
-    { const uint32_t k = (g << kGrpShift) + lane; if (k < t) sum += a.seg[k].valid; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)sum, d, 64), hi = __shfl_xor((uint32_t)(sum >> 32), d, 64);
-        sum += ((unsigned long long)hi << 32) | lo;
-    }
-    return sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;
-}
-
-// gather: one wave per four tiles copies their valid slots, in slot (= offset) order, to the final list.
-// Workgroup 0 also writes the header / per-channel counts and re-arms the pool allocator; all
-// workgroups clear the other parity's group counters for the next launch.
-__global__ __launch_bounds__(256) void gather_tiles(CompactArgs a)
-{
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-        if (a.zero1) for (uint32_t k = gtid; k < a.n_grp1; k += gsz) a.zero1[k] = 0;
-        if (a.zero2) for (uint32_t k = gtid; k < a.n_grp2; k += gsz) a.zero2[k] = 0;
-    }
-    // per-channel counts: one wave per channel, spread over the grid (a 64-channel batch would otherwise
-    // serialise 128 prefix sums on one wave: 50 us)
-    if (a.write_header) {
-        for (uint32_t c0 = blockIdx.x * 4 + wave; c0 < a.n_channels; c0 += gridDim.x * 4) {
-            uint32_t b = tile_prefix(a, c0 * a.tiles_per_channel, lane);
-            uint32_t e = tile_prefix(a, (c0 + 1) * a.tiles_per_channel, lane);
-            b = b < a.max_out ? b : a.max_out;
-            e = e < a.max_out ? e : a.max_out;
-            if (lane == 0) a.chan_counts[c0] = e - b;
-        }
-    }
-    if (blockIdx.x == 0 && wave == 0 && a.write_header) {
-        const unsigned long long total = tile_prefix(a, a.n_tiles, lane); // (saturating)
-        if (lane == 0) {
-            a.hdr->total_found = total;
-            a.hdr->n_out = total < a.max_out ? total : a.max_out;
-            // flags were cleared by the demod kernel; bits are OR-ed in (another wave may add INCOMPLETE below)
-            if (total > a.max_out) atomicOr(&a.hdr->flags, ADSB_FLAG_TRUNCATED);
-            a.hdr->alloc = 0;     // ready for the next launch
-            if (a.hdr_pub) {
-                a.hdr_pub[0] = total < a.max_out ? total : a.max_out;
-                a.hdr_pub[1] = total;
-                if (total > a.max_out) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_TRUNCATED);
-                a.hdr_pub[3] = 0;
-            }
-        }
-    }
-    // Four consecutive tiles per wave (a quarter of the waves, one round of them per CU): the position of the
-    // first comes from the group counters (wave-cooperative), the others follow by adding the valid counts.
-    const uint32_t t_end = a.tile_first + a.tile_count;
-    const uint32_t t0 = a.tile_first + (blockIdx.x * 4 + wave) * 4;
-    if (t0 >= t_end) return;
-    Seg mine;
-    mine.base = kNoBase; mine.cand = 0; mine.valid = 0; mine.decoded = 0;
-    if (lane < 4 && t0 + lane < t_end) mine = a.seg[t0 + lane];
-    // the tiles' own records and the counts the position is summed from are independent loads: issued together
-    uint32_t pos0 = a.out_start ? 0u : tile_prefix(a, t0, lane);
-    uint32_t base[4], cand[4], valid[4], pos[4], maxcand = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        base[k] = __shfl(mine.base, k, 64);
-        cand[k] = __shfl(mine.cand, k, 64);
-        valid[k] = __shfl(mine.valid, k, 64);
-    }
-    {
-        unsigned long long run = pos0; // (saturating like tile_prefix)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            pos[k] = a.out_start ? ((t0 + k < t_end) ? a.out_start[t0 + k] : 0xFFFFFFFFu)
-                                 : (run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run);
-            run += valid[k];
-            if (valid[k] == 0 || pos[k] >= a.max_out) cand[k] = 0; // nothing of this tile is wanted
-            if (cand[k] && base[k] == kNoBase) { // its slots were dropped but its frames are wanted: host re-plans
-                if (lane == 0) {
-                    atomicOr(&a.hdr->retry, 1u);
-                    // visible to device-side consumers too: the list has holes until the host has re-planned
-                    atomicOr(&a.hdr->flags, ADSB_FLAG_INCOMPLETE);
-                    if (a.hdr_pub) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_INCOMPLETE);
-                }
-                cand[k] = 0;
-            }
-            maxcand = cand[k] > maxcand ? cand[k] : maxcand;
-        }
-    }
-    if (maxcand == 0) return;
-    if (maxcand <= 64) {
-        // the usual case: 16 lanes per tile, all four tiles side by side
-        const uint32_t g = lane >> 4, l = lane & 15;
-        const uint32_t gb = g == 0 ? base[0] : g == 1 ? base[1] : g == 2 ? base[2] : base[3];
-        const uint32_t gc = g == 0 ? cand[0] : g == 1 ? cand[1] : g == 2 ? cand[2] : cand[3];
-        uint32_t gp = g == 0 ? pos[0] : g == 1 ? pos[1] : g == 2 ? pos[2] : pos[3];
-        const uint2 *src = reinterpret_cast<const uint2 *>(a.slots + (gc ? gb : 0u)); // 24-byte records, 8-byte aligned
-        for (uint32_t i0 = 0; i0 < maxcand; i0 += 16) { // (wave-uniform trip count)
-            const uint32_t i = i0 + l;
-            uint32_t w[6] = {0, 0, 0, 0, 0, 0xFF0000u};
-            if (i < gc) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const uint2 v = src[(size_t)i * 3 + k];
-                    w[2 * k] = v.x;
-                    w[2 * k + 1] = v.y;
-                }
-            }
-            const bool ok = (i < gc) && (((w[5] >> 16) & 0xFFu) != 0xFFu);
-            const uint32_t m = (uint32_t)(__ballot(ok) >> (16 * g)) & 0xFFFFu;
-            const uint32_t dst = gp + (uint32_t)__builtin_popcount(m & ((1u << l) - 1u));
-            if (ok && dst < a.max_out) {
-                uint2 *d = reinterpret_cast<uint2 *>(a.out + dst);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) d[k] = make_uint2(w[2 * k], w[2 * k + 1]);
-            }
-            gp += (uint32_t)__builtin_popcount(m);
-        }
-        return;
-    }
-    // a tile with many survivors (coarse or constant input): the whole wave takes the tiles one after the other
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (cand[k] == 0) continue;
-        const uint2 *src = reinterpret_cast<const uint2 *>(a.slots + base[k]);
-        uint32_t p = pos[k];
-        for (uint32_t i0 = 0; i0 < cand[k]; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            uint32_t w[6] = {0, 0, 0, 0, 0, 0xFF0000u};
-            if (i < cand[k]) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const uint2 v = src[(size_t)i * 3 + q];
-                    w[2 * q] = v.x;
-                    w[2 * q + 1] = v.y;
-                }
-            }
-            const bool ok = (i < cand[k]) && (((w[5] >> 16) & 0xFFu) != 0xFFu);
-            const unsigned long long m = __ballot(ok);
-            const uint32_t dst = p + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            if (ok && dst < a.max_out) {
-                uint2 *d = reinterpret_cast<uint2 *>(a.out + dst);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) d[q] = make_uint2(w[2 * q], w[2 * q + 1]);
-            }
-            p += (uint32_t)__builtin_popcountll(m);
-        }
-    }
-}
-
-hipError_t launch_gather(hipStream_t s, const CompactArgs &a, hipEvent_t e0, hipEvent_t e1)
-{
-    uint32_t blocks = (a.tile_count + 15) / 16; // 4 waves x 4 tiles
-    if (blocks == 0) blocks = 1; // the header still has to be written
-    hipExtLaunchKernelGGL(gather_tiles, dim3(blocks), dim3(256), 0, s, e0, e1, 0, a);
-    return hipGetLastError();
 }
 
 // ---- field decode (what AdsbPacket::new computes, src/adsb/packet.rs:25-49) -----------------------

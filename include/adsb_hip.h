@@ -319,15 +319,16 @@ int adsb_sample_type(const adsb_ctx *ctx);
 /* ---- measurement / test helpers (bench.py, tests; not part of the reference's surface) ----- */
 /*
  * With timing on (on = N > 0), every N-th adsb_demod_device_async() attaches HIP events to the
- * demodulation kernel's dispatch and to the ordering pass's (on the stream they run on).  adsb_timing_read()
+ * scan kernel's dispatch and to the finishing kernel's (on the stream they run on).  adsb_timing_read()
  * waits for the stream, returns the mean milliseconds per launch of each since the last read
  * (at most the 512 most recent launches) and clears the log.
  */
 int adsb_timing_enable(adsb_ctx *ctx, int on);
-/* The three kernels of a launch separately: the scan kernel (demod_tiles: squared magnitude + preamble/DF17 gate
- * over every sample + PPM slice of the gate's survivors -- the kernel that reads the IQ bytes), the finishing kernel
- * (finish_candidates: CRC-24, single-bit repair and ordering inside a tile, one lane per survivor; reported as
- * decode_ms) and the ordering pass (gather_tiles).  adsb_timing_read reports the first and the last. */
+/* The two kernels of a launch separately: the scan kernel (demod_tiles: magnitude + preamble/DF17 gate over every
+ * sample + PPM slice of the gate's survivors -- the kernel that reads the IQ bytes) and the finishing kernel
+ * (finish_order: CRC-24, single-bit repair and the ordered frame list in one pass over the survivors; reported as
+ * decode_ms_mean).  order_ms_mean is 0 since round 3 (the separate ordering pass was fused into finish_order).
+ * adsb_timing_read reports the scan and the finishing kernel. */
 int adsb_timing_read3(adsb_ctx *ctx, double *scan_ms_mean, double *decode_ms_mean, double *order_ms_mean,
                       uint32_t *n_launches);
 int adsb_timing_read(adsb_ctx *ctx, double *demod_ms_mean, double *order_ms_mean,
