@@ -80,6 +80,17 @@ struct adsb_ctx {
     unsigned long long *stamps = nullptr; // cycle counters of diagnostic builds (64 bytes per tile with -DADSB_TILE_STAMPS=1)
     size_t stamps_bytes = 0;
     int scan = adsbk::kScanRoot;    // which i8 scan kernel (ADSB_SCAN=nsq selects the A/B kernel at adsb_create)
+    // The one-dispatch path for small buffers (adsbk::launch_small): per result set a pinned, device-writable blob
+    // [32-byte header | frames | u64 sequence number] and a device counter; a pinned input buffer for adsb_demod().
+    struct Small {
+        bool enabled = true, ready = false;
+        char *blob[2] = {nullptr, nullptr};
+        uint32_t cap = 0;            // frames per blob
+        uint32_t *done = nullptr;    // device: 2 words
+        char *in_host = nullptr;     // pinned copy of adsb_demod()'s buffer (allocated on first use)
+        uint64_t seq = 0;
+        uint64_t max_samples = 0;    // longest buffer the path takes
+    } sm;
     bool pool_off = false;          // adsb_debug_pool_limit: the shared slot pool hands out nothing (test knob)
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
@@ -158,6 +169,9 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     (void)hipFree(c->scratch);
     (void)hipFree(c->stamps);
     (void)hipFree(c->lb);
+    (void)hipFree(c->sm.done);
+    for (char *b : c->sm.blob) if (b) (void)hipHostFree(b);
+    if (c->sm.in_host) (void)hipHostFree(c->sm.in_host);
     if (c->own_aux && c->aux) (void)hipStreamDestroy(c->aux);
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -186,6 +200,7 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     // CU) and the round-3 A/B kernel whose gate works on n = I^2+Q^2 (no root per sample, but 2 bytes of LDS per
     // sample: four workgroups per CU; 10 % fewer VALU slots, 12 % slower -- DESIGN.md section 5.3): ADSB_SCAN=nsq in
     // the environment at adsb_create selects it.
+    if (const char *sp = getenv("ADSB_SMALL_PATH")) c->sm.enabled = !(sp[0] == '0');
     if (const char *sc = getenv("ADSB_SCAN")) {
         if (strcmp(sc, "nsq") == 0) c->scan = adsbk::kScanNsq;
         else if (strcmp(sc, "root") == 0 || sc[0] == 0) c->scan = adsbk::kScanRoot;
@@ -426,6 +441,135 @@ static void view_launch(adsb_ctx *c, uint32_t set)
     c->trk_done = false;
 }
 
+// ---- the one-dispatch path for small buffers --------------------------------------------------------------------------
+// (adsbk::demod_small: every workgroup scans its tile, the last one to finish checks and orders all survivors and writes
+// header + frames straight into pinned host memory, then a sequence number the host polls.)  One HIP call per buffer
+// instead of a copy, three launches, two result copies and their synchronisations: what the reference's own buffer sizes
+// (20 000 samples, adsb.rs:77-79; MTU-sized reads, adsb.rs:59-64) need.
+static size_t small_blob_bytes(uint32_t cap) { return 32 + sizeof(adsb_frame) * (size_t)cap + 16; }
+static uint64_t *small_seq_word(adsb_ctx *c, uint32_t set)
+{
+    return reinterpret_cast<uint64_t *>(c->sm.blob[set] + 32 + sizeof(adsb_frame) * (size_t)c->sm.cap);
+}
+
+static int small_init(adsb_ctx *c)
+{
+    if (c->sm.ready) return ADSB_OK;
+    if (!c->sm.enabled) return ADSB_E_STATE;
+    const uint64_t tile = (uint64_t)adsbk::tile_offsets(c->cfg.sample_type);
+    c->sm.max_samples = std::min<uint64_t>(c->cfg.max_samples, tile * adsbk::kFinishTilesPerWg + kWindow);
+    // a buffer of n samples has at most n - 240 frames (one per offset: SURVEY F8)
+    c->sm.cap = (uint32_t)std::min<uint64_t>(c->cfg.max_out, c->sm.max_samples);
+    if (c->sm.cap == 0) return ADSB_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    for (int k = 0; k < 2; ++k) {
+        // coherent (fine-grained) host memory: the device's writes are visible to the polling host while the stream runs
+        if (hipHostMalloc((void **)&c->sm.blob[k], small_blob_bytes(c->sm.cap), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            c->sm.enabled = false;
+            return ADSB_E_NOMEM;
+        }
+        std::memset(c->sm.blob[k], 0, 32);
+        *small_seq_word(c, (uint32_t)k) = 0;
+    }
+    if (hipMalloc((void **)&c->sm.done, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipMemsetAsync(c->sm.done, 0, 2 * sizeof(uint32_t), c->stream) != hipSuccess) {
+        c->sm.enabled = false;
+        return ADSB_E_NOMEM;
+    }
+    c->sm.ready = true;
+    return ADSB_OK;
+}
+
+// Can this buffer take the one-dispatch path?  (Not while the caller redirects results into a blob of its own.)
+static bool small_fits(adsb_ctx *c, size_t n_samples)
+{
+    return c->sm.enabled && !c->ext_blob && !c->fused_pass_only && !c->own_aux && n_samples > (size_t)kWindow &&
+           small_init(c) == ADSB_OK && n_samples <= c->sm.max_samples;
+}
+
+// Enqueues one buffer (device-visible memory: pinned host or device, 16-byte aligned) as launch `launch_idx`; like
+// adsb_demod_device_async for one channel, in one dispatch.  *seq_out = the value the blob's sequence word will carry.
+static int small_launch(adsb_ctx *c, const void *iq, size_t n_samples, uint64_t *seq_out)
+{
+    HIPCHK(hipSetDevice(c->cfg.device));
+    c->last_iq = iq;
+    c->last_channels = 1;
+    c->last_samples = n_samples;
+    c->last_stride = n_samples;
+    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type);
+    c->last_tiles = c->last_tpc;
+    c->last_base = c->stream_base;
+    c->launched = true;
+    c->fields_current = false;
+    c->trk_done = false;
+    const uint32_t i = c->launch_idx, set = i & 1u;
+    adsb_ctx::ResultSet &r = c->rs[set];
+    adsbk::DemodArgs da = demod_args(c, r, 0, c->last_tiles, true);
+    da.hdr_pub = reinterpret_cast<uint64_t *>(c->sm.blob[set]);
+    adsbk::FinishArgs fa = finish_args(c, r, i, 0, c->last_tiles, false);
+    fa.out = reinterpret_cast<adsb_frame *>(c->sm.blob[set] + 32);
+    fa.hdr_pub = reinterpret_cast<uint64_t *>(c->sm.blob[set]);
+    fa.max_out = c->sm.cap;
+    adsbk::SmallArgs sa{};
+    sa.done = c->sm.done + set;
+    sa.seq_host = small_seq_word(c, set);
+    sa.seq = ++c->sm.seq;
+    HIPCHK(adsbk::launch_small(c->stream, c->cfg.sample_type, c->mag_mode, c->scan, da, fa, sa));
+    c->last_out = fa.out;
+    c->last_cap = fa.max_out;
+    c->last = set;
+    r.li.iq = iq; r.li.channels = 1; r.li.samples = n_samples; r.li.stride = n_samples;
+    r.li.base = c->last_base; r.li.tpc = c->last_tpc; r.li.tiles = c->last_tiles; r.li.out = c->last_out;
+    r.li.cap = c->last_cap; r.li.idx = i; r.li.valid = true;
+    c->launch_idx = i + 1u;
+    *seq_out = sa.seq;
+    return ADSB_OK;
+}
+
+// Waits (polling pinned memory, no HIP call on the usual path) until result set `set` carries sequence number `seq`.
+static int small_wait(adsb_ctx *c, uint32_t set, uint64_t seq)
+{
+    volatile uint64_t *w = small_seq_word(c, set);
+    for (uint32_t spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        if (spins > (1u << 22)) { // ~ tens of milliseconds of polling: let the runtime tell what happened
+            HIPCHK(hipSetDevice(c->cfg.device));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(w, __ATOMIC_ACQUIRE) != seq) return ADSB_E_STATE;
+            break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return ADSB_OK;
+}
+
+static int sync_header(adsb_ctx *c);
+// Hands the finished list of result set `set` (a small launch that small_wait has seen complete) to the caller.
+static int small_collect(adsb_ctx *c, uint32_t set, adsb_frame *out, size_t max_out, size_t *n_out, uint64_t *total_found,
+                         uint32_t *flags)
+{
+    const uint64_t *hdr = reinterpret_cast<const uint64_t *>(c->sm.blob[set]);
+    if (hdr[2] & ADSB_FLAG_INCOMPLETE) {
+        // slot-pool overflow (pathological input): the standard re-run path completes the blob in place
+        const uint32_t newest = c->last;
+        view_launch(c, set);
+        int rc = sync_header(c);
+        view_launch(c, newest);
+        if (rc != ADSB_OK) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    uint64_t n = hdr[0];
+    uint32_t fl = (uint32_t)hdr[2] & ~ADSB_FLAG_INCOMPLETE;
+    if (n > max_out) { n = max_out; fl |= ADSB_FLAG_TRUNCATED; }
+    if (n) std::memcpy(out, c->sm.blob[set] + 32, sizeof(adsb_frame) * (size_t)n);
+    *n_out = (size_t)n;
+    if (total_found) *total_found = hdr[1];
+    if (flags) *flags = fl;
+    return ADSB_OK;
+}
+
 // Slot-pool overflow (far more gate survivors than max_out + one tile): redo the tiles that feed
 // the first max_out frames in batches whose survivors fit.  Counts from the first pass are exact,
 // so the plan is made on the host.  Only pathological inputs get here.
@@ -469,7 +613,7 @@ static int rerun_in_batches(adsb_ctx *c, adsb_ctx::ResultSet &r)
         const uint64_t pub_flags = c->hdr_host->flags;
         HIPCHK(hipMemcpyAsync(&r.hdr->flags, &c->hdr_host->flags, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         if (c->last_out != r.out) // the launch wrote into a caller-owned blob: [n_out | total | flags | 0 | frames]
-            HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(c->last_out) - 16, &pub_flags, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(c->last_out) - 16, &pub_flags, sizeof(uint64_t), hipMemcpyDefault, c->stream)); // (the blob may be pinned host memory: the small-buffer path)
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return rc;
@@ -514,7 +658,7 @@ extern "C" int adsb_fetch(adsb_ctx *c, adsb_frame *out, size_t max_out, size_t *
     uint32_t fl = c->hdr_host->flags;
     if (n > max_out) { n = max_out; fl |= ADSB_FLAG_TRUNCATED; }
     adsb_ctx::ResultSet &r = c->rs[c->last];
-    if (n) HIPCHK(hipMemcpyAsync(out, c->last_out, sizeof(adsb_frame) * n, hipMemcpyDeviceToHost, c->aux));
+    if (n) HIPCHK(hipMemcpyAsync(out, c->last_out, sizeof(adsb_frame) * n, hipMemcpyDefault, c->aux)); // (device memory, or the small-buffer path's pinned blob)
     std::vector<uint64_t> pre;
     if (per_channel_counts) {
         pre.resize((size_t)c->last_channels + 1);
@@ -671,6 +815,24 @@ extern "C" int adsb_demod(adsb_ctx *c, const void *iq, size_t n_samples, adsb_fr
     if (n_samples < (size_t)kWindow) return ADSB_E_SHORT;
     if (n_samples > c->cfg.max_samples) return ADSB_E_CAPACITY;
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (small_fits(c, n_samples)) {
+        // a small buffer (the reference's own sizes): copy it into pinned memory the device reads directly, ONE dispatch,
+        // the frames come back through pinned memory too -- no copy commands, no stream synchronisation
+        if (!c->sm.in_host &&
+            hipHostMalloc((void **)&c->sm.in_host, (size_t)c->sm.max_samples * c->bps + 64, hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            c->sm.enabled = false;
+        } else {
+            std::memcpy(c->sm.in_host, iq, n_samples * c->bps);
+            uint64_t seq = 0;
+            int rc = small_launch(c, c->sm.in_host, n_samples, &seq);
+            if (rc != ADSB_OK) return rc;
+            const uint32_t set = c->last;
+            rc = small_wait(c, set, seq);
+            if (rc != ADSB_OK) return rc;
+            return small_collect(c, set, out, max_out, n_out, nullptr, flags);
+        }
+    }
     HIPCHK(hipMemcpyAsync(c->staging, iq, n_samples * c->bps, hipMemcpyHostToDevice, c->stream));
     int rc = adsb_demod_device_async(c, c->staging, 1, n_samples, n_samples);
     if (rc != ADSB_OK) return rc;
@@ -895,10 +1057,16 @@ struct adsb_feed {
     size_t prev_start = 0, prev_len = 0; // demodulated region of the previous buffer's slot (samples)
     struct Entry {
         bool launched = false;
+        bool small = false;        // went through the one-dispatch path: results in the ctx's pinned blob `set`
+        uint64_t seq = 0;          // ... complete when its sequence word carries this
         uint32_t set = 0;
         uint64_t first_sample = 0; // stream position of the buffer's first own sample
     } q[2];
     adsbk::Header *hdr_host = nullptr;
+    size_t headroom = 0;           // samples in front of every ring slot's data (carry mode: room for the 240-sample tail)
+    const char *prev_host = nullptr; // where the previous buffer's demodulated region starts in HOST memory (nullptr: it
+                                     // only exists in a device staging slot)
+    uint32_t prev_ring = 0;          // ... and the ring slot that holds it
 };
 
 extern "C" void adsb_feed_close(adsb_feed *f)
@@ -937,6 +1105,7 @@ extern "C" int adsb_feed_open(adsb_ctx *c, const adsb_feed_cfg *cfg, adsb_feed *
     if (f->cfg.ring_slots < 2) f->cfg.ring_slots = 3;
     f->bps = c->bps;
     bool ok = hipStreamCreateWithFlags(&f->copy, hipStreamNonBlocking) == hipSuccess;
+    f->headroom = kWindow; // (240 samples = 480 / 960 bytes: keeps the data 16-byte aligned)
     const size_t slot_bytes = (cfg->max_chunk + (size_t)kWindow + 8) * f->bps;
     for (int k = 0; k < 2 && ok; ++k)
         ok = hipMalloc((void **)&f->dev[k], slot_bytes) == hipSuccess &&
@@ -945,7 +1114,7 @@ extern "C" int adsb_feed_open(adsb_ctx *c, const adsb_feed_cfg *cfg, adsb_feed *
     for (uint32_t k = 0; k < f->cfg.ring_slots && ok; ++k) {
         char *p = nullptr;
         hipEvent_t e = nullptr;
-        ok = hipHostMalloc((void **)&p, cfg->max_chunk * f->bps, hipHostMallocDefault) == hipSuccess &&
+        ok = hipHostMalloc((void **)&p, (cfg->max_chunk + f->headroom) * f->bps, hipHostMallocDefault) == hipSuccess &&
              hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (p) f->ring.push_back(p);
         if (e) f->ring_done.push_back(e);
@@ -967,6 +1136,7 @@ extern "C" int adsb_feed_ready(adsb_feed *f)
     if (f->popped == f->pushed) return ADSB_E_STATE;
     const uint32_t s = (uint32_t)(f->popped & 1u);
     if (!f->q[s].launched) return 1;
+    if (f->q[s].small) return __atomic_load_n(small_seq_word(f->c, f->q[s].set), __ATOMIC_ACQUIRE) == f->q[s].seq ? 1 : 0;
     HIPCHK(hipSetDevice(f->c->cfg.device));
     const hipError_t e = hipEventQuery(f->kern_done[s]);
     if (e == hipSuccess) return 1;
@@ -994,7 +1164,7 @@ extern "C" int adsb_feed_acquire(adsb_feed *f, void **host_slot)
     int rc = feed_ring_slot(f, &r);
     if (rc != ADSB_OK) return rc;
     f->acquired = (int)r;
-    *host_slot = f->ring[r];
+    *host_slot = f->ring[r] + f->headroom * f->bps;
     return ADSB_OK;
 }
 
@@ -1008,38 +1178,72 @@ extern "C" int adsb_feed_push(adsb_feed *f, const void *iq_host, size_t n)
     adsb_ctx *c = f->c;
     HIPCHK(hipSetDevice(c->cfg.device));
     uint32_t r = 0;
+    char *data = nullptr; // the buffer's samples in the pinned ring
     if (f->acquired >= 0) {
         r = (uint32_t)f->acquired;
-        if (iq_host && iq_host != f->ring[r]) std::memcpy(f->ring[r], iq_host, n * f->bps);
+        data = f->ring[r] + f->headroom * f->bps;
+        if (iq_host && iq_host != data) std::memcpy(data, iq_host, n * f->bps);
         f->acquired = -1;
     } else {
         int rc = feed_ring_slot(f, &r);
         if (rc != ADSB_OK) return rc;
-        std::memcpy(f->ring[r], iq_host, n * f->bps);
+        data = f->ring[r] + f->headroom * f->bps;
+        std::memcpy(data, iq_host, n * f->bps);
     }
     f->ring_next = (r + 1) % (uint32_t)f->ring.size();
 
     const uint32_t s = (uint32_t)(f->pushed & 1u);
     const size_t tail = (f->cfg.carry && f->pushed) ? std::min<size_t>(kWindow, f->prev_len) : 0;
-    const size_t start = ((size_t)kWindow - tail) / 8 * 8; // 16-byte aligned start of the demodulated region
     const size_t len = tail + n;
-    // this staging slot was last read by the launch two buffers ago
-    if (f->kern_pending[s]) HIPCHK(hipStreamWaitEvent(f->copy, f->kern_done[s], 0));
-    HIPCHK(hipMemcpyAsync(f->dev[s] + (start + tail) * f->bps, f->ring[r], n * f->bps, hipMemcpyHostToDevice, f->copy));
-    HIPCHK(hipEventRecord(f->ring_done[r], f->copy));
-    f->ring_busy[r] = 1;
-    if (tail) // the last `tail` samples of what the previous launch saw, device to device (its H2D is earlier on this stream)
-        HIPCHK(hipMemcpyAsync(f->dev[s] + start * f->bps, f->dev[s ^ 1u] + (f->prev_start + f->prev_len - tail) * f->bps,
-                              tail * f->bps, hipMemcpyDeviceToDevice, f->copy));
-    HIPCHK(hipEventRecord(f->h2d_done[s], f->copy));
-
     adsb_feed::Entry &e = f->q[s];
     e.first_sample = f->consumed;
     e.launched = false;
+    e.small = false;
+    const uint64_t base = f->cfg.carry ? f->consumed - tail : 0;
+
+    // ---- small buffers: one dispatch, samples read from the ring and frames written to pinned memory by the device ----
+    // (carry mode: the tail of the previous buffer is copied in front of this one on the host -- 480 or 960 bytes --
+    // which needs that buffer in host memory and a 16-byte aligned start, i.e. the usual 240-sample tail)
+    if (len >= (size_t)kWindow && small_fits(c, len) && (tail == 0 || (f->prev_host && (tail * f->bps) % 16 == 0))) {
+        char *start = data - tail * f->bps;
+        if (tail) std::memcpy(start, f->prev_host + (f->prev_len - tail) * f->bps, tail * f->bps);
+        int rc = adsb_set_stream_base(c, base);
+        if (rc == ADSB_OK) rc = small_launch(c, start, len, &e.seq);
+        if (rc != ADSB_OK) return rc;
+        e.launched = true;
+        e.small = true;
+        e.set = c->last;
+        f->ring_busy[r] = 0; // (the slot is not reused before this buffer has been popped: two in flight, >= 2 slots)
+        f->prev_host = start;
+        f->prev_ring = r;
+        f->prev_start = 0;
+        f->prev_len = len;
+        f->consumed += n;
+        f->pushed++;
+        return ADSB_OK;
+    }
+
+    const size_t start = ((size_t)kWindow - tail) / 8 * 8; // 16-byte aligned start of the demodulated region
+    // this staging slot was last read by the launch two buffers ago
+    if (f->kern_pending[s]) HIPCHK(hipStreamWaitEvent(f->copy, f->kern_done[s], 0));
+    HIPCHK(hipMemcpyAsync(f->dev[s] + (start + tail) * f->bps, data, n * f->bps, hipMemcpyHostToDevice, f->copy));
+    HIPCHK(hipEventRecord(f->ring_done[r], f->copy));
+    f->ring_busy[r] = 1;
+    if (tail) { // the last `tail` samples of what the previous launch saw
+        if (f->prev_host) { // ... which went through the one-dispatch path: they are in the ring (host memory)
+            HIPCHK(hipMemcpyAsync(f->dev[s] + start * f->bps, f->prev_host + (f->prev_len - tail) * f->bps, tail * f->bps,
+                                  hipMemcpyHostToDevice, f->copy));
+            HIPCHK(hipEventRecord(f->ring_done[f->prev_ring], f->copy)); // that slot is read once more: not reusable before
+            f->ring_busy[f->prev_ring] = 1;
+        } else // ... device to device (its H2D is earlier on this stream)
+            HIPCHK(hipMemcpyAsync(f->dev[s] + start * f->bps, f->dev[s ^ 1u] + (f->prev_start + f->prev_len - tail) * f->bps,
+                                  tail * f->bps, hipMemcpyDeviceToDevice, f->copy));
+    }
+    HIPCHK(hipEventRecord(f->h2d_done[s], f->copy));
+
     if (len >= (size_t)kWindow) {
         HIPCHK(hipStreamWaitEvent(c->stream, f->h2d_done[s], 0));
         // after a pop of an older launch the ctx may "view" that launch: the next enqueue starts from the newest state
-        const uint64_t base = f->cfg.carry ? f->consumed - tail : 0;
         int rc = adsb_set_stream_base(c, base);
         if (rc == ADSB_OK) rc = adsb_demod_device_async(c, f->dev[s] + start * f->bps, 1, len, len);
         if (rc != ADSB_OK) return rc;
@@ -1048,6 +1252,7 @@ extern "C" int adsb_feed_push(adsb_feed *f, const void *iq_host, size_t n)
         HIPCHK(hipEventRecord(f->kern_done[s], c->aux)); // THIS launch's kernels and results (not the stream's tail)
         f->kern_pending[s] = true;
     }
+    f->prev_host = nullptr;
     f->prev_start = start;
     f->prev_len = len;
     f->consumed += n;
@@ -1068,6 +1273,11 @@ extern "C" int adsb_feed_pop(adsb_feed *f, adsb_frame *out, size_t max_out, size
     if (first_sample) *first_sample = e.first_sample;
     f->popped++;
     if (!e.launched) return ADSB_OK; // (carry mode, fewer than 240 samples so far: nothing decodable yet)
+    if (e.small) { // the device wrote header and frames into pinned memory: poll its sequence word, copy, done
+        int rc = small_wait(c, e.set, e.seq);
+        if (rc != ADSB_OK) return rc;
+        return small_collect(c, e.set, out, max_out, n_out, nullptr, flags);
+    }
     adsb_ctx::ResultSet &r = c->rs[e.set];
     // results travel on the copy stream, behind this launch's ordering pass only -- not behind the kernels of the
     // buffer pushed after it, which share the ctx stream

@@ -106,6 +106,13 @@ struct FinishArgs {
     uint64_t *hdr_pub;         // optional caller-owned copy of {n_out, total_found, flags} (4 x u64)
 };
 
+// demod_small: the one-dispatch path for buffers of at most kFinishTilesPerWg tiles
+struct SmallArgs {
+    uint32_t *done;      // device word, zero between launches: workgroups that have finished their tile
+    uint64_t *seq_host;  // host-visible (pinned) word the last workgroup writes `seq` to when header and list are complete
+    uint64_t seq;
+};
+
 // mag_mode: how v_cvt_pk_u8_f32 rounds on this device (decided once per ctx by probe_cvt):
 //   0: truncates as is; 1: truncates once MODE.fp_round(f32) is set to round-toward-zero;
 //   2: rounds to nearest regardless -> subtract 0.5 first.
@@ -122,6 +129,9 @@ hipError_t launch_finish(hipStream_t s, const FinishArgs &a, hipEvent_t e0 = nul
 hipError_t launch_empty_result(hipStream_t s, Header *hdr, uint64_t *hdr_pub, uint64_t *chan_prefix, uint32_t n_channels,
                                hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 constexpr int kFinishTilesPerWg = 32;
+// scan + finish in one dispatch for 1..kFinishTilesPerWg tiles; the list goes to f.out / f.hdr_pub (host-visible memory)
+hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, const DemodArgs &p, const FinishArgs &f,
+                        const SmallArgs &sm);
 
 bool tile_stamps_built(); // -DADSB_TILE_STAMPS=1 diagnostic build: DemodArgs::stamps holds 64 bytes per tile
 

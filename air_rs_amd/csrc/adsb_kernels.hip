@@ -1009,8 +1009,10 @@ __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *ca
 #ifndef ADSB_SCAN_WAVES
 #define ADSB_SCAN_WAVES 4
 #endif
+// The tile body: everything one workgroup does for one tile (`first` = it is the launch's first workgroup: it clears
+// the result header's flags).  smem: Lds<ST, SCAN>::kTotal bytes, 16-byte aligned.
 template <int ST, int MAGMODE, int SCAN>
-__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoot) ? 8 : ADSB_SCAN_WAVES) void demod_tiles(DemodArgs p)
+__device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t tile, const bool first, unsigned char *smem)
 {
     typedef Lds<ST, SCAN> L;
     typedef TileCfg<ST> TC; // tile length of this sample type
@@ -1018,7 +1020,6 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoo
     constexpr bool NSQ = L::kNsq;
     static_assert(kThreads / 64 <= 4, "misc[4 + wave] must stay below misc[8]");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[L::kTotal];
     mag_t *mag = reinterpret_cast<mag_t *>(smem);
     uint32_t *img = reinterpret_cast<uint32_t *>(smem); // (nsq) the same bytes as pairs of biased squared magnitudes
     uint32_t *cand = reinterpret_cast<uint32_t *>(smem + L::kOffCand);
@@ -1037,7 +1038,6 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoo
     ts_seg[8] = (uint32_t)ts_prev; // s_memtime next to the s_memrealtime above: the shader clock under this load
 #endif
     {
-        const uint32_t tile = p.tile_first + blockIdx.x;
         const TilePos tp = tile_pos<TC::kTileT>(p, tile);
         const uint64_t sample0 = tp.sample0;
         const uint32_t n_valid = tp.n_valid;
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoo
         if constexpr (NSQ) nsq_issue_loads(p, tp, tid, raw_a, raw_b);
         else issue_tile_loads<ST>(p, tp, true, tid, raw);
         TSTAMP(0); // prologue, loads issued
-        if (tid == 0 && blockIdx.x == 0) {
+        if (tid == 0 && first) {
             p.hdr->retry = 0;
             if (p.count_groups) { // first pass of a launch: the finishing kernel ORs this launch's flags in
                 p.hdr->flags = 0;
@@ -1234,6 +1234,13 @@ __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoo
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
+template <int ST, int MAGMODE, int SCAN>
+__global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoot) ? 8 : ADSB_SCAN_WAVES) void demod_tiles(DemodArgs p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Lds<ST, SCAN>::kTotal];
+    scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+}
+
 // ---- CRC-24 + single-bit repair of the sliced survivors (demod.rs:71-81; crc.rs:10-65) --------------------------
 // Byte-wise table of the Mode-S CRC-24 (generator 0x1FFF409, MSB first, init 0, no final XOR: crc.rs:10-40):
 // kCrcTab[v] = (v * x^24) mod G.  crc' = (crc << 8) ^ kCrcTab[(crc >> 16) ^ byte] over the 11 data bytes.
@@ -1410,17 +1417,14 @@ __device__ __forceinline__ uint32_t finish_big_tile(const FinishArgs &a, const S
 #ifndef ADSB_FIN_ABL
 #define ADSB_FIN_ABL 0 // measurement only (wrong results): 1 no exchange, 2 no CRC / search, 3 no stores of the list, 4 empty kernel
 #endif
-__global__ __launch_bounds__(kFinThreads) void finish_order(FinishArgs a)
+constexpr int kFinLdsWords = 256 + 128 + 2 * kFinTiles; // tables, per-tile counts, per-tile positions
+// What workgroup `blk` of `n_blk` does (lds: kFinLdsWords words).
+__device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t blk, const uint32_t n_blk, uint32_t *lds)
 {
-#if ADSB_FIN_ABL == 4
-    if (a.max_out != 0xFFFFFFF1u) return;
-#endif
-    __shared__ uint32_t crc_tab[256];
-    __shared__ uint32_t syn_sorted[128];
-    __shared__ uint32_t counts[kFinTiles]; // valid frames per tile of this workgroup
-    __shared__ uint32_t tpos[kFinTiles];   // position of each tile's first frame in the final list
+    uint32_t *crc_tab = lds, *syn_sorted = lds + 256;
+    uint32_t *counts = lds + 384;            // valid frames per tile of this workgroup
+    uint32_t *tpos = lds + 384 + kFinTiles;  // position of each tile's first frame in the final list
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, sub = lane & 15;
-    const uint32_t blk = blockIdx.x, n_blk = gridDim.x;
     const uint32_t tile0 = a.tile_first + blk * kFinTiles, t_end = a.tile_first + a.tile_count;
 
     // ---- this wave's 8 tiles, 4 per pass: one lane per survivor ------------------------------------------------------
@@ -1634,11 +1638,76 @@ __global__ __launch_bounds__(kFinThreads) void finish_order(FinishArgs a)
     }
 }
 
+__global__ __launch_bounds__(kFinThreads) void finish_order(FinishArgs a)
+{
+#if ADSB_FIN_ABL == 4
+    if (a.max_out != 0xFFFFFFF1u) return;
+#endif
+    __shared__ uint32_t lds[kFinLdsWords];
+    finish_block(a, blockIdx.x, gridDim.x, lds);
+}
+
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a, hipEvent_t e0, hipEvent_t e1)
 {
     const uint32_t blocks = (a.tile_count + kFinTiles - 1) / kFinTiles;
     if (blocks == 0) return hipSuccess;
     hipExtLaunchKernelGGL(finish_order, dim3(blocks), dim3(kFinThreads), 0, s, e0, e1, 0, a);
+    return hipGetLastError();
+}
+
+// ---- small buffers: scan + finish in ONE dispatch, results straight into host memory --------------------------------------
+// A buffer of at most kFinTiles tiles (the reference's own buffers: 20 000 samples = 2 tiles, adsb.rs:77-79; an SDR's MTU-
+// sized reads, adsb.rs:59-64) is not worth three host calls per kernel and a copy each way: one workgroup per tile runs the
+// tile body, the workgroup that finishes LAST (a counter in device memory; agent-scope release / acquire around it) runs
+// the finishing block over all tiles, writes header and frames through the caller's pointer -- pinned host memory the
+// device can write -- and then, behind a system-scope fence, a sequence number the host polls.  The samples are read
+// from pinned host memory the same way.  Per buffer the host makes ONE call (the launch).
+static_assert(kFinThreads == kThreads, "the small-buffer kernel runs both bodies in one workgroup shape");
+template <int ST, int MAGMODE, int SCAN>
+__global__ __launch_bounds__(kThreads, 4) void demod_small(DemodArgs p, FinishArgs f, SmallArgs sm)
+{
+    constexpr int kScanBytes = Lds<ST, SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kScanBytes > kFinBytes ? kScanBytes : kFinBytes];
+    __shared__ uint32_t last_flag;
+    scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    // hand-off to whichever workgroup arrives last (cdna_hip_programming.md Guideline 16: every storing wave drains its
+    // stores, the workgroup's barrier, one lane's agent-scope release, then the counter; the reader acquires)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t prev = __hip_atomic_fetch_add(sm.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = prev == gridDim.x - 1 ? 1u : 0u;
+        if (last_flag) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    finish_block(f, 0, 1, reinterpret_cast<uint32_t *>(smem));
+    // everything is written (list and header, through f.out / f.hdr_pub): tell the host
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *sm.done = 0; // re-armed for the next launch on this result set
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope: the host reads what this kernel wrote
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(sm.seq_host, sm.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, const DemodArgs &p, const FinishArgs &f,
+                        const SmallArgs &sm)
+{
+    if (p.tile_count == 0 || p.tile_count > (uint32_t)kFinTiles) return hipErrorInvalidValue;
+    dim3 grid(p.tile_count), block(kThreads);
+    if (sample_type == ADSB_SAMPLE_I16) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I16, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
+    else if (scan == kScanNsq) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanNsq>), grid, block, 0, s, p, f, sm);
+    else if (mag_mode == 0) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
+    else if (mag_mode == 1) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 1, kScanRoot>), grid, block, 0, s, p, f, sm);
+    else hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 2, kScanRoot>), grid, block, 0, s, p, f, sm);
     return hipGetLastError();
 }
 

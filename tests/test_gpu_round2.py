@@ -126,6 +126,33 @@ def test_zero_copy_consumer_sees_incomplete_flag_and_repair(gpu, oracle):
         _eq(frames, want)
 
 
+def test_small_buffer_path_equals_three_kernel_path(gpu, oracle, monkeypatch):
+    """adsb_demod() on buffers of up to 32 tiles takes ONE dispatch (scan + finish + ordered list into pinned memory);
+    ADSB_SMALL_PATH=0 keeps the copy + two kernels + fetch.  Same frames either way, on ragged sizes around the tile
+    and 32-tile edges, for i8 (both scan kernels) and CS16, incl. dense input (every offset a frame) and a capacity
+    smaller than the frame count."""
+    sizes = [241, 1000, 16384 + 240, 16384 + 241, 20000, 3 * 16384 + 777, 32 * 16384 + 240, 32 * 16384 + 241, 600_000]
+    for st, scan in ((A.ADSB_SAMPLE_I8, "root"), (A.ADSB_SAMPLE_I8, "nsq"), (A.ADSB_SAMPLE_I16, "root")):
+        monkeypatch.setenv("ADSB_SCAN", scan)
+        cfg = A.synth_default(seed=61, slot_len=500)
+        if st == A.ADSB_SAMPLE_I16:
+            cfg.amp_shift = 5
+        data = A.synth_fill_host(cfg, st, 0, 0, max(sizes))
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ADSB_SMALL_PATH", mode)
+            with A.AdsbDemod(sample_type=st, max_samples=max(sizes), max_out=1 << 15) as d:
+                got[mode] = [d.demod(data[:n]) for n in sizes]
+                dense = d.demod(np.zeros((50_000, 2), dtype=data.dtype))          # 49 760 frames > max_out: truncated
+                assert dense[1] & A.ADSB_FLAG_TRUNCATED and len(dense[0]) == 1 << 15
+                assert (dense[0]["offset"] == np.arange(1 << 15)).all() and not dense[0]["bytes"].any()
+        for n, (a, fa), (b, fb) in zip(sizes, got["1"], got["0"]):
+            rc, want, cnt = oracle.process_buffer(data[:n])
+            assert fa == fb == 0 and rc == 0
+            _eq(a, want)
+            _eq(b, want)
+
+
 def test_scan_kernel_selection(gpu, monkeypatch):
     """ADSB_SCAN at adsb_create: default and "root" = the product's i8 scan kernel, "nsq" = the A/B kernel, anything
     else is refused; CS16 has one kernel."""

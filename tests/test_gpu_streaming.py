@@ -12,6 +12,20 @@ import air_rs_amd as A
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", params=["small-path", "three-kernels"], autouse=True)
+def small_path(request):
+    """Every test of this module runs twice: with the one-dispatch path for small buffers (adsbk::demod_small: buffers of
+    up to 32 tiles go through ONE kernel that reads the pinned ring and writes the frames into pinned memory) and with
+    it switched off (ADSB_SMALL_PATH=0 at adsb_create: copy + scan + finish + result copies, as for large buffers)."""
+    old = os.environ.get("ADSB_SMALL_PATH")
+    os.environ["ADSB_SMALL_PATH"] = "1" if request.param == "small-path" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("ADSB_SMALL_PATH", None)
+    else:
+        os.environ["ADSB_SMALL_PATH"] = old
+
+
 def _eq(got, want):
     assert len(got) == len(want), (len(got), len(want))
     if len(got):
