@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1]): 2 MSPS-format i8 IQ, a 1 GiB synthetic buffer per GPU, resident
 in HBM before the timed region; one step = one pass of the fused magnitude + preamble/DF17 gate + PPM
-slice + CRC-24 (+ ordering pass) over that buffer.  With N > 1 ranks the stream is time-sharded: rank
+slice (the scan kernel) + CRC-24 / repair + ordered frame list (the finishing kernel) over that buffer.  With N > 1 ranks the stream is time-sharded: rank
 g owns offsets [g*(n-240), (g+1)*(n-240)) of one long stream and generates its own slice plus the
 240-sample read halo (no input exchange); frames carry absolute stream offsets (adsb_set_stream_base); every
 launch writes its ordered frame list into a slot of an 8-launch bucket and one RCCL gather per bucket moves
@@ -322,9 +322,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": f"adsbk::demod_tiles<{args.sample_type}, {dem.scan}>", "kernel_ms": round(demod_ms, 4),
-                         "kernel_does": "scan kernel: reads every IQ byte once; fused (squared) magnitude + preamble/DF17 gate + PPM slice "
-                                        "of the gate survivors (their CRC-24 / repair / ordering is finish_candidates)",
-                         "finish_pass_ms": round(decode_ms, 4), "order_pass_ms": round(order_ms, 4), "launches_timed": n_timed,
+                         "kernel_does": "scan kernel: reads every IQ byte once; fused magnitude + preamble/DF17 gate + PPM slice "
+                                        "of the gate survivors (their CRC-24 / repair / ordering is finish_order, the launch's second kernel)",
+                         "finish_order_ms": round(decode_ms, 4), "launches_timed": n_timed,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "read_ceiling_gbps": round(float(bps) * n / (ceil_ms * 1e-3) / 1e9, 1)},
         }

@@ -257,6 +257,29 @@ def test_bench_three_ranks_share_one_gpu(gpu):
     assert g["frames"] == want, (g["frames"], want)
 
 
+# ---- BASELINE.json configs[1] at full size: the WHOLE 1 GiB list against the oracle -------------
+def test_config2_1GiB_full_output_equals_oracle(gpu, oracle):
+    """The bench workload itself (536 870 912 i8 samples generated on the device, one launch): every frame of the HIP
+    list -- offset, 14 bytes, status, repaired bit -- against the CPU oracle over the same samples.  (~6-10 s of one
+    host core; bench.py repeats the comparison in its own JSON line as `parity_check`.)"""
+    import torch
+    n = 1 << 29
+    cfg = A.synth_default()
+    with A.AdsbDemod(max_samples=n, max_out=n // cfg.slot_len + 8192, host_staging=False,
+                     stream=torch.cuda.current_stream().cuda_stream) as d:
+        iq = torch.empty(2 * n, dtype=torch.int8, device="cuda")
+        d.synth_fill_device(cfg, 0, 0, n, iq.data_ptr())
+        d.demod_device_async(iq.data_ptr(), n)
+        frames, counts, total, flags = d.fetch()
+        host = iq.cpu().numpy().reshape(n, 2)
+        del iq
+    torch.cuda.empty_cache()
+    assert flags == 0 and total == len(frames)
+    rc, want, found = oracle.process_buffer(host, max_out=1 << 20)
+    assert rc == 0 and found == len(want) > 250_000
+    _eq(frames, want)
+
+
 # ---- BASELINE.json configs[2] at full size: 16 GiB of i8 IQ resident on one MI355X ------------------------------
 def test_config3_16GiB_whole_buffer(gpu, oracle):
     import torch

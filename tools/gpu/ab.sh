@@ -14,6 +14,6 @@ for rep in $(seq 1 ${REPS:-2}); do
     ADSB_SCAN=$scan ADSB_HIP_LIB=$lib timeout -k 10 120 python bench.py --steps 30 --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['cold_start']
-print('$spec', 'scan_ms', r['kernel_ms'], 'finish_ms', r['finish_pass_ms'], 'order_ms', r['order_pass_ms'], 'ms_per_step', d['ms_per_step'], 'frac', r['frac'], 'cold_scan_ms', c['kernel_ms'], 'frames', d['config']['frames_per_step'], 'ceil', r['read_ceiling_gbps'])" | tee -a $out
+print('$spec', 'scan_ms', r['kernel_ms'], 'finish_ms', r['finish_order_ms'], 'ms_per_step', d['ms_per_step'], 'frac', r['frac'], 'cold_scan_ms', c['kernel_ms'], 'frames', d['config']['frames_per_step'], 'ceil', r['read_ceiling_gbps'])" | tee -a $out
   done
 done

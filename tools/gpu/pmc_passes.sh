@@ -23,8 +23,7 @@ for f in glob.glob(os.environ.get("PMC_OUT","gpurun_out/pmc") + "/*/**/*counter_
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "demod_tiles" in k: k = "demod_tiles"
-        elif "finish_candidates" in k: k = "finish_candidates"
-        elif "gather_tiles" in k: k = "gather_tiles"
+        elif "finish_order" in k: k = "finish_order"
         elif "read_only" in k: k = "read_only"
         else: continue
         res[k][row["Counter_Name"]].append(float(row["Counter_Value"]))

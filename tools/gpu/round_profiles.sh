@@ -11,6 +11,10 @@ tools/gpu/pmc_passes.sh > gpurun_out/pmc_out.txt 2>&1 || { tail -20 gpurun_out/p
 cp gpurun_out/pmc/summary.json gpurun_out/r_pmc_summary_i8.json
 BENCH_ARGS="--sample-type i16" tools/gpu/pmc_passes.sh > gpurun_out/pmc_out_i16.txt 2>&1 || { tail -20 gpurun_out/pmc_out_i16.txt; exit 1; }
 cp gpurun_out/pmc/summary.json gpurun_out/r_pmc_summary_i16.json
+BENCH_ARGS="--scan nsq" tools/gpu/pmc_passes.sh > gpurun_out/pmc_out_nsq.txt 2>&1 || { tail -20 gpurun_out/pmc_out_nsq.txt; exit 1; }
+cp gpurun_out/pmc/summary.json gpurun_out/r_pmc_summary_nsq.json
+python bench.py --steps 30 --warmup 3 --no-cpu-baseline --scan nsq > gpurun_out/r_bench_nsq.json 2>gpurun_out/r_bench_nsq.err || exit 1
+python bench.py --steps 20 --warmup 5 > gpurun_out/r_bench_driver_flags.json 2>gpurun_out/r_bench_driver_flags.err || exit 1
 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --sample-type i16 > gpurun_out/r_bench_cs16.json 2>gpurun_out/r_bench_cs16.err || exit 1
 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --samples 8589934592 > gpurun_out/r_bench_16g.json 2>gpurun_out/r_bench_16g.err || exit 1
 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --samples 8589934592 --sample-type i16 > gpurun_out/r_bench_cs16_16g.json 2>gpurun_out/r_bench_cs16_16g.err || exit 1
@@ -18,6 +22,7 @@ python bench.py --steps 30 --warmup 3 --no-cpu-baseline --channels 64 > gpurun_o
 rm -rf gpurun_out/prof16 && mkdir -p gpurun_out/prof16
 TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof16 -o stats -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --samples 8589934592 > gpurun_out/prof16_bench.json 2> gpurun_out/prof16.err
 f=$(find gpurun_out/prof16 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r_kernel_stats_16g.csv
-for f in r_bench r_bench_cs16 r_bench_16g r_bench_cs16_16g r_bench_64ch; do python3 -c "
+[ -x tools/bench/feed_bench ] && timeout -k 10 300 tools/bench/feed_bench > gpurun_out/r_feed_bench.txt 2>&1
+for f in r_bench r_bench_driver_flags r_bench_nsq r_bench_cs16 r_bench_16g r_bench_cs16_16g r_bench_64ch; do python3 -c "
 import json; d=json.load(open('gpurun_out/$f.json')); r=d['roofline']; fp=r.get('fused_pass',{})
-print('$f', r['kernel'], 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'GB/s', r['achieved'], 'frac', r['frac'], 'ceil', r['read_ceiling_gbps'], 'finish_ms', r.get('finish_pass_ms'), 'order_ms', r.get('order_pass_ms'))"; done
+print('$f', r['kernel'], 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'GB/s', r['achieved'], 'frac', r['frac'], 'ceil', r['read_ceiling_gbps'], 'finish_ms', r.get('finish_order_ms'))"; done

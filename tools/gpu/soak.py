@@ -15,11 +15,23 @@ ap.add_argument("--seed", type=int, default=1)
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 orc = Oracle()
-ctx = {(A.ADSB_SAMPLE_I8, "tiles"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 19),
-       (A.ADSB_SAMPLE_I16, "tiles"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 22, max_out=1 << 19),
-       # small frame capacity: dense inputs (coarse alphabets, constant stretches) overflow the slot pool and are re-planned
-       (A.ADSB_SAMPLE_I8, "small"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 20, max_out=3000),
-       (A.ADSB_SAMPLE_I16, "small"): A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=1 << 20, max_out=3000)}
+def make(st, max_samples, max_out, scan="root", small_path="1"):
+    os.environ["ADSB_SCAN"], os.environ["ADSB_SMALL_PATH"] = scan, small_path   # read by adsb_create
+    return A.AdsbDemod(sample_type=st, max_samples=max_samples, max_out=max_out)
+
+
+# every kernel variant: i8 root scan (the product's), i8 nsq scan (the A/B kernel), CS16; the one-dispatch path for small
+# buffers on (default) and off; and small frame capacities (dense inputs overflow the slot pool and are re-planned)
+ctx = {(A.ADSB_SAMPLE_I8, "root"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19),
+       (A.ADSB_SAMPLE_I8, "nsq"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="nsq"),
+       (A.ADSB_SAMPLE_I8, "root-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, small_path="0"),
+       (A.ADSB_SAMPLE_I8, "nsq-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="nsq", small_path="0"),
+       (A.ADSB_SAMPLE_I16, "root"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19),
+       (A.ADSB_SAMPLE_I16, "root-3k"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19, small_path="0"),
+       (A.ADSB_SAMPLE_I8, "small"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000),
+       (A.ADSB_SAMPLE_I8, "small-nsq"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, scan="nsq"),
+       (A.ADSB_SAMPLE_I8, "small-3k"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, small_path="0"),
+       (A.ADSB_SAMPLE_I16, "small"): make(A.ADSB_SAMPLE_I16, 1 << 20, 3000)}
 t0 = time.time()
 runs = fails = frames_total = 0
 t_note = t0
@@ -28,18 +40,23 @@ while time.time() - t0 < args.seconds:
         t_note = time.time()
         print(f"  ... {runs} buffers, {fails} mismatches after {t_note - t0:.0f} s", flush=True)
     st = A.ADSB_SAMPLE_I8 if rng.random() < 0.7 else A.ADSB_SAMPLE_I16
-    kern = "tiles"
+    kern = str(rng.choice(["root", "nsq", "root-3k", "nsq-3k"])) if st == A.ADSB_SAMPLE_I8 else str(rng.choice(["root", "root-3k"]))
     n = int(rng.choice([rng.integers(240, 4000), rng.integers(4000, 200000), rng.integers(200000, 3000000)]))
     dense = rng.random() < 0.06
     if dense:
-        kern, n = "small", min(n, 1 << 20)
+        kern = str(rng.choice(["small", "small-nsq", "small-3k"])) if st == A.ADSB_SAMPLE_I8 else "small"
+        n = min(n, 1 << 20)
     cfg = A.synth_default(seed=int(rng.integers(1, 1 << 40)), slot_len=int(rng.choice([300, 600, 2000, 9000])))
     cfg.noise_div = int(rng.choice([3, 8, 18, 60, 200]))
+    level = int(rng.integers(0, 4))  # now and then: samples at full scale (i8: |I|, |Q| >= 125 switch a tile's gate to integer compares)
     cfg.pct_flip_data = int(rng.integers(0, 30)); cfg.pct_flip_crc = int(rng.integers(0, 10)); cfg.pct_flip_two = int(rng.integers(0, 10))
     cfg.frame_pct = int(rng.choice([0, 30, 100]))
     if st == A.ADSB_SAMPLE_I16:
         cfg.amp_shift = int(rng.integers(0, 8))
     iq = A.synth_fill_host(cfg, st, int(rng.integers(0, 4)), int(rng.integers(0, 1 << 30)), n)
+    if level == 0 and st == A.ADSB_SAMPLE_I8 and n > 1000:
+        pos = rng.integers(0, n, size=max(1, n // 5000))
+        iq[pos] = rng.choice(np.array([-128, -127, -126, -125, 125, 126, 127], dtype=np.int8), size=(len(pos), 2))
     if dense:  # every offset of a constant stretch is a frame; a two-level alphabet makes many ties
         mode = int(rng.integers(0, 3))
         if mode == 0:

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def derived(d, samples, bps):
@@ -29,6 +29,8 @@ def derived(d, samples, bps):
 
 i8 = json.load(open(os.path.join(G, "r_pmc_summary_i8.json")))
 i16 = json.load(open(os.path.join(G, "r_pmc_summary_i16.json")))
+nsq_path = os.path.join(G, "r_pmc_summary_nsq.json")
+nsq = json.load(open(nsq_path)) if os.path.exists(nsq_path) else None
 old = json.load(open(os.path.join(P, "pmc_summary.json")))
 before = old.get("before_the_split") or {"note": "demod_tiles with the whole decode inside (round 1 .. mid round 2)",
                                          "i8": old.get("i8", {}).get("demod_tiles", {}).get("derived"),
@@ -36,28 +38,34 @@ before = old.get("before_the_split") or {"note": "demod_tiles with the whole dec
                                          "cs16": old.get("cs16", {}).get("demod_tiles", {}).get("derived"),
                                          "round_1": old.get("round_1")}
 new = {
-    "round": "round 2",
+    "round": "round 3",
     "note": "rocprofv3 --pmc passes over `bench.py --steps 4 --warmup 1` (tools/gpu/pmc_passes.sh; `--sample-type i16` for CS16), "
             "mean per launch of the named kernel on the 1 GiB workload; FETCH_SIZE is in KiB and is doubled per MI355X_MICROARCH.md "
             "(gfx950 reports half of a wide streaming read); SQ_* cycle counters are in quad-cycles summed over waves, GRBM_GUI_ACTIVE "
-            "is summed over the 8 XCDs.  demod_tiles = the scan kernel (magnitude + gate + PPM slice of survivors), "
-            "finish_candidates = CRC-24 / repair / ordering of the survivors, gather_tiles = the ordering pass.",
+            "is summed over the 8 XCDs.  demod_tiles = the scan kernel (magnitude + gate + PPM slice of survivors; i8: the root scan on "
+            "16384-offset tiles, 8 workgroups per CU), finish_order = CRC-24 / repair of the survivors + the ordered list.",
     "demod_tiles_hbm_bytes_per_launch": int(i8["demod_tiles"]["FETCH_SIZE"] * 1024 * 2),
     "demod_tiles_i16_hbm_bytes_per_launch": int(i16["demod_tiles"]["FETCH_SIZE"] * 1024 * 2),
     "algorithmic_bytes_per_launch": 1073741824,
     "i8": {"demod_tiles": {"derived": derived(i8["demod_tiles"], 1 << 29, 2), "raw": i8["demod_tiles"]},
-           "finish_candidates": i8.get("finish_candidates"), "gather_tiles": i8.get("gather_tiles"),
+           "finish_order": i8.get("finish_order"),
            "read_only_kernel": i8.get("read_only")},
     "cs16": {"demod_tiles": {"derived": derived(i16["demod_tiles"], 1 << 28, 4), "raw": i16["demod_tiles"]},
-             "finish_candidates": i16.get("finish_candidates")},
+             "finish_order": i16.get("finish_order")},
+    # the round-3 A/B kernel (ADSB_SCAN=nsq: gate on I^2+Q^2, no root per sample, 2 bytes of LDS per sample -> 4 workgroups
+    # per CU instead of 8): fewer VALU slots, more waiting
+    "i8_nsq_scan": ({"demod_tiles": {"derived": derived(nsq["demod_tiles"], 1 << 29, 2), "raw": nsq["demod_tiles"]}} if nsq else None),
     "before_the_split": before,
     # the scan kernel's PMC rows as it was trimmed after the split (each measured by the same passes, one MI355X box each)
-    "demod_tiles_i8_history": old.get("demod_tiles_i8_history") or [
+    "demod_tiles_i8_history": [
         {"what": "whole decode inside demod_tiles (round 1 .. mid round 2)", "valu_instructions_per_wave": 1539, "valu_slots_per_wave": 1674},
         {"what": "the split: CRC / repair / ordering in finish_candidates", "valu_instructions_per_wave": 1432, "valu_slots_per_wave": 1567.1},
         {"what": "n_valid masking out of the DF17 block", "valu_instructions_per_wave": 1411.7, "valu_slots_per_wave": 1546.8},
         {"what": "tile loads: sweep constant in the SGPR offset; one register for the DF17 bit constant", "valu_instructions_per_wave": 1386.3, "valu_slots_per_wave": 1521.4},
         {"what": "slicer: SDWA byte compare + add-with-carry per bit", "valu_instructions_per_wave": 1367.4, "valu_slots_per_wave": 1502.5},
+        {"what": "round 3: 16384-offset tiles (runs of 32; per wave per tile, i.e. per HALF as many samples as the rows above), 19 KB of LDS, "
+                 "8 workgroups per CU", "valu_instructions_per_wave": round(i8["demod_tiles"]["SQ_INSTS_VALU"] / i8["demod_tiles"]["SQ_WAVES"], 1),
+         "valu_slots_per_wave": round(i8["demod_tiles"]["SQ_ACTIVE_INST_VALU"] / i8["demod_tiles"]["SQ_WAVES"], 1)},
     ],
     "demod_tiles_cs16_history": old.get("demod_tiles_cs16_history") or [
         {"what": "whole decode inside demod_tiles", "valu_instructions_per_wave": 1155, "valu_slots_per_wave": 1223},
@@ -67,7 +75,8 @@ new = {
     ],
 }
 json.dump(new, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
-for src, dst in (("r_bench.json", "bench.json"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
+for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"),
+                 ("r_feed_bench.txt", "feed_bench.txt"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
                  ("r_bench_cs16_16g.json", "bench_cs16_16GiB.json"), ("r_bench_64ch.json", "bench_64_channels.json"),
                  ("r_kernel_stats.csv", "kernel_stats.csv"), ("r_kernel_stats_16g.csv", "kernel_stats_16GiB.csv")):
     if os.path.exists(os.path.join(G, src)):
