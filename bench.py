@@ -338,6 +338,7 @@ def main():
         if gather_check is not None:
             out["gather_check"] = gather_check
         out["warmup_requested"] = args.warmup
+        out["warmup_launches_total"] = warmup_total  # every untimed launch before the K timed ones (= "warmup")
         out["warmup_breakdown"] = {"cold_run_warmup": args.warmup, "cold_run_timed_steps": args.steps, "settle_launches": settle_launches,
                                    "reported_run_warmup": args.warmup} if settle_s > 0 else {"reported_run_warmup": args.warmup}
         out["settle"] = {"seconds": settle_s, "launches": settle_launches,
