@@ -991,19 +991,17 @@ __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *ca
 }
 
 // [phase:end]
-// demod_tiles: one workgroup = one tile; the hardware dispatcher keeps 4 workgroups (16 waves) resident per CU (a
-// tile's image takes 33-36 KB of LDS) and starts the next tile as soon as one retires, which staggers the phases of
-// co-resident workgroups.  Per tile:
-//   phase 1  the tile's raw IQ (16-byte loads, all in flight at once) becomes the LDS image: i8/kScanNsq: pairs of
-//            biased I^2+Q^2; i8/kScanRoot (A/B kernel) and CS16: floor(sqrt) magnitudes;                ... barrier
-//   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase_nsq / gate_phase);                 ... barrier
+// demod_tiles: one workgroup = one tile; the hardware dispatcher starts the next tile as soon as one retires, which
+// staggers the phases of a CU's co-resident workgroups.  Per tile:
+//   phase 1  the tile's raw IQ (16-byte loads, all in flight at once) becomes the LDS image: i8/kScanRoot and CS16:
+//            floor(sqrt) magnitudes (u8 / u16); i8/kScanNsq (the A/B kernel): pairs of biased I^2+Q^2;     ... barrier
+//   phase 2  preamble + DF17 gate over the tile's offsets (gate_phase / gate_phase_nsq);                    ... barrier
 //   phase 3  every survivor gets a frame slot, its offset and its 14 sliced bytes; CRC-24, repair and ordering are
-//            finish_candidates' (below).
+//            finish_order's (below).
 // Measured alternatives: persistent workgroups drawing tiles from per-XCD ticket counters with
-// the next tile's loads issued before phase 3 (no slot ever waits for the dispatcher or for its samples) run the same
-// tile in ~10 % more VALU instructions (loop-carried registers, SGPR spills) and come out 7 % slower: in-kernel cycle
-// stamps (tools/gpu/tile_stamps.py) show the SIMDs VALU-saturated while any three of the four slots compute, so
-// filling the gaps buys nothing -- the instruction count is what bounds this kernel.
+// the next tile's loads issued before phase 3 run the same tile in ~10 % more VALU instructions (loop-carried
+// registers, SGPR spills) and come out 7 % slower; several tiles per workgroup with the next tile's loads in flight
+// need 147 VGPRs (3 waves per SIMD): 0.25-0.27 ms against 0.182.  The instruction count is what bounds this kernel.
 // Waves per SIMD the register allocation is held to = workgroups per CU the LDS image allows (4 waves per workgroup):
 // 8 for the i8 root scan (u8 magnitudes: 19 KB), 4 for the 16-bit images (nsq, CS16: 35-38 KB).
 #ifndef ADSB_SCAN_WAVES
