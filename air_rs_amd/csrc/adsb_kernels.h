@@ -20,11 +20,12 @@ constexpr int kRun = ADSB_KRUN; // consecutive offsets one lane slides over, per
 constexpr int kTile = 2 * kThreads * kRun; // offsets owned by one workgroup (16384 at kRun 32)
 constexpr int kHalo = 256;      // >= 239 extra samples so PPM never leaves the tile; 16-aligned
 constexpr int kMag = kTile + kHalo;
-// Both sample types keep 16-bit values per sample in LDS (i8: n = I^2+Q^2 + a bias, or its root in the A/B kernel;
-// CS16: u16 magnitudes): runs of 32 offsets = 16384-offset tiles, 33-36 KB, four workgroups per CU.  (Runs of 64
-// with 16-bit values take 66 KB: two workgroups per CU, two waves per SIMD -- far too few to hide the gate's latencies.)
+// CS16 keeps u16 magnitudes in LDS.  Runs of 16 offsets = 8192-offset tiles, 19 KB: the kernel's 85 VGPRs then allow
+// five workgroups per CU (20 waves) where 16384-offset tiles (35 KB) allowed four -- and the finer tiles overlap better:
+// 0.177 -> 0.161 ms per GiB (0.76 -> 0.83 of 8 TB/s; profiles/r03_ab_cs16_tile8192.txt).  Holding the kernel to 80 or
+// 64 VGPRs for six or eight workgroups spills and is slower (0.171 / 0.188 ms).
 #ifndef ADSB_KRUN_I16
-#define ADSB_KRUN_I16 32
+#define ADSB_KRUN_I16 16
 #endif
 constexpr int kRunI16 = ADSB_KRUN_I16;
 template <int ST> struct TileCfg {

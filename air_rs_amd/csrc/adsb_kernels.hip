@@ -287,7 +287,7 @@ template <int ST, int SCAN = kScanRoot> struct Lds {
     static constexpr bool kNsq = ST == ADSB_SAMPLE_I8 && SCAN == kScanNsq;
     static constexpr int kMagBytes = kNsq ? kNsqPhys * 4 : TileCfg<ST>::kMagT * (int)sizeof(mag_t);
     static constexpr int kOffCand = kMagBytes;                 // one word per run of 32 offsets: survivor bitmap
-    static constexpr int kOffList = kOffCand + 2 * kThreads * 4 * (TileCfg<ST>::kRunT / 32); // kListCap x u16
+    static constexpr int kOffList = kOffCand + 2 * kThreads * 4 * ((TileCfg<ST>::kRunT + 31) / 32); // kListCap x u16
     static constexpr int kOffMisc = kOffList + kListCap * 2;   // 16 x u32
     static constexpr int kTotal = kOffMisc + 64;
 };
@@ -550,7 +550,7 @@ template <int RUN, int NT>
 __device__ __forceinline__ void gate_collect(uint32_t *candA, uint32_t *candB, uint16_t *list, uint32_t *count,
                                              const uint32_t tid, const uint32_t n_valid)
 {
-    constexpr int WPR = RUN / 32;
+    constexpr int WPR = (RUN + 31) / 32; // (runs of 16: one word per run, its low half used)
     const uint32_t sa = tid * RUN, sb = (tid + NT) * RUN;
     const uint32_t va = n_valid > sa ? (n_valid - sa) : 0u, vb = n_valid > sb ? (n_valid - sb) : 0u;
     uint32_t words[2 * WPR];
@@ -610,10 +610,10 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
                                            uint32_t *count, const uint32_t tid, const uint32_t n_valid,
                                            HOOK hook = HOOK())
 {
-    static_assert(RUN % GROUP == 0 && (RUN == 32 || RUN == 64), "steps are taken GROUP at a time; 1 or 2 bitmap words per run");
-    constexpr int WPR = RUN / 32; // bitmap words per run
+    static_assert(RUN % GROUP == 0 && (RUN == 16 || RUN == 32 || RUN == 64), "steps are taken GROUP at a time; 1 or 2 bitmap words per run");
+    constexpr int WPR = (RUN + 31) / 32; // bitmap words per run (a run of 16 uses the low half of its word)
     constexpr int SPG = 16 / (int)sizeof(typename MagT<ST>::type); // magnitudes per 16-byte LDS granule
-    // Survivor bitmap: WPR words per run (offset 32 w + b of the tile is bit b of word w), owned by this
+    // Survivor bitmap: WPR words per run (offset min(RUN, 32) w + b of the tile is bit b of word w), owned by this
     // lane.  The rare path ORs bits straight into LDS so the unrolled steps carry no mask registers.
     uint32_t *candA = cand + WPR * tid, *candB = cand + WPR * (tid + NT);
 #pragma unroll
@@ -1109,12 +1109,13 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
         if (total != 0x7FFFFFFFu) total = 0; // survivors are counted (phase 2 stays alive) but not handed over
 #endif
         const bool dense = total > (uint32_t)kSparseCap;
+        constexpr int kBitsPerWord = TC::kRunT < 32 ? TC::kRunT : 32; // offsets per survivor-bitmap word (gate_phase)
         u32x4 cw = {0, 0, 0, 0};
         uint32_t cnt = 0, my_first = 0;
         if (dense) {
             // dense fallback: ordered compaction of the bitmap by workgroup-wide prefix sums
-            // bitmap: offset 32 w + b of the tile is bit b of word w; words 4*tid .. 4*tid+3 per thread
-            if (4 * tid < (uint32_t)(TC::kTileT / 32)) cw = reinterpret_cast<const u32x4 *>(cand)[tid];
+            // bitmap: offset kBitsPerWord w + b of the tile is bit b of word w; words 4*tid .. 4*tid+3 per thread
+            if (4 * tid < (uint32_t)(TC::kTileT / kBitsPerWord)) cw = reinterpret_cast<const u32x4 *>(cand)[tid];
             cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) +
                   __builtin_popcount(cw.w);
             uint32_t incl = cnt;
@@ -1185,7 +1186,7 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
                             const uint32_t b = __builtin_ctz(bits);
                             bits &= bits - 1;
                             if (idx >= chunk && idx < chunk + kListCap)
-                                list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
+                                list[idx - chunk] = (uint16_t)((4 * tid + k) * kBitsPerWord + b);
                             ++idx;
                         }
                     }

@@ -89,7 +89,7 @@ def test_magnitude_i16(dem16, oracle):
     assert (dem16.magnitudes(iq) == oracle.get_magnitude(iq)).all()
 
 
-@pytest.mark.parametrize("n", [240, 241, 255, 271, 272, 1000, 8192 + 239, 8192 + 241, 16384 + 239, 16384 + 240,
+@pytest.mark.parametrize("n", [240, 241, 255, 271, 272, 1000, 8192 + 239, 8192 + 240, 8192 + 241, 16384 + 239, 16384 + 240,
                                16384 + 241, 20000, 32768 + 239, 32768 + 240, 32768 + 241, 65536 + 240, 100003])
 def test_synthetic_sizes_i8(dem8, oracle, n):
     cfg = A.synth_default(seed=100 + n, slot_len=600)

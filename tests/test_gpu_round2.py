@@ -131,7 +131,9 @@ def test_small_buffer_path_equals_three_kernel_path(gpu, oracle, monkeypatch):
     ADSB_SMALL_PATH=0 keeps the copy + two kernels + fetch.  Same frames either way, on ragged sizes around the tile
     and 32-tile edges, for i8 (both scan kernels) and CS16, incl. dense input (every offset a frame) and a capacity
     smaller than the frame count."""
-    sizes = [241, 1000, 16384 + 240, 16384 + 241, 20000, 3 * 16384 + 777, 32 * 16384 + 240, 32 * 16384 + 241, 600_000]
+    # (tile = 16384 offsets for i8, 8192 for CS16: the 32-tile edge of the one-dispatch path lies at both)
+    sizes = [241, 1000, 8192 + 240, 16384 + 240, 16384 + 241, 20000, 3 * 16384 + 777, 32 * 8192 + 240, 32 * 8192 + 241,
+             32 * 16384 + 240, 32 * 16384 + 241, 600_000]
     for st, scan in ((A.ADSB_SAMPLE_I8, "root"), (A.ADSB_SAMPLE_I8, "nsq"), (A.ADSB_SAMPLE_I16, "root")):
         monkeypatch.setenv("ADSB_SCAN", scan)
         cfg = A.synth_default(seed=61, slot_len=500)
@@ -399,7 +401,7 @@ def test_cs16_gate_paths_agree_with_the_oracle(gpu, oracle):
         # 1. full range: magnitudes up to 46340
         check(rng.integers(-32768, 32768, size=(200_000, 2)).astype(np.int16))
         check(rng.choice(np.array([-32768, -32767, 32766, 32767, 0], dtype=np.int16), size=(100_000, 2)))
-        # 2. a stream of frames, with full-scale spikes in tiles 1, 4 and 7 only (tile = 16384 offsets)
+        # 2. a stream of frames, with full-scale spikes in three 16384-offset stretches only (two 8192-offset CS16 tiles each)
         cfg = A.synth_default(seed=314, slot_len=700, amp_shift=7)
         iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I16, 0, 0, 300_000)
         n_clean = check(iq)
