@@ -1508,23 +1508,6 @@ __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t
             if (lane == 0) __hip_atomic_store(lb_a + blk, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t grp = blk / kFinFan, r = blk % kFinFan;
             bool failed = false;
-            // polls `word` (where `want`) until it carries this launch's tag; all lanes leave together
-            auto wait_word = [&](const uint64_t *word, const bool want) -> unsigned long long {
-                unsigned long long v = 0;
-                bool ready = !want;
-                uint32_t spins = 0;
-                while (!__all(ready)) {
-                    if (!ready) {
-                        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ready = (v >> 32) == (tag >> 32);
-                        if (!ready) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++spins > kLbSpinLimit) { failed = true; ready = true; v = 0; }
-                        }
-                    }
-                }
-                return want ? (v & 0xFFFFFFFFull) : 0ull;
-            };
             auto wave_sum = [&](unsigned long long x) {
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) {
@@ -1560,16 +1543,51 @@ __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t
                 } while (!__all(ok));
                 before = wave_sum(acc);
             } else {
-                // the aggregates before this one inside its 64: one per lane
-                const unsigned long long in_grp = wave_sum(wait_word(lb_a + (size_t)grp * kFinFan + lane, lane < r));
-                if (r == kFinFan - 1 && lane == 0) { // the last of its 64 publishes their sum (a 64's frames fit 32 bits)
-                    const unsigned long long sum64 = in_grp + total;
-                    __hip_atomic_store(lb_s + grp, tag | (sum64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : sum64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                // the sums of the earlier 64s: lane l takes l, l + 64, ... (their last workgroups have lower indices than this one)
-                unsigned long long earlier = 0;
-                for (uint32_t k0 = 0; k0 < grp; k0 += 64) earlier += wait_word(lb_s + k0 + lane, k0 + lane < grp); // (wave-uniform trip count)
-                before = in_grp + wave_sum(earlier);
+                // two levels: the aggregates before this one inside its 64 (one per lane) and the sums of the earlier 64s
+                // (lane l takes l, l + 64, ...; published by workgroups with lower indices than this one).  Both sets of
+                // loads are in flight together and re-read until they carry the tag: one round trip when the others are
+                // ahead, as they mostly are -- not one per level and per 64 earlier sums.  The last of a 64 publishes its
+                // 64's sum as soon as its own in-group words are complete (it does not wait for the earlier 64s: no chain).
+                unsigned long long in_grp = 0, earlier = 0;
+                bool in_done = false, e_done = grp == 0;
+                uint32_t spins = 0;
+                do {
+                    unsigned long long vi = tag, e_acc = 0;
+                    bool e_ok = true;
+                    if (!in_done && lane < r) vi = __hip_atomic_load(lb_a + (size_t)grp * kFinFan + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!e_done) {
+                        for (uint32_t k0 = 0; k0 < grp; k0 += 64u * 8u) { // (wave-uniform trip count; eight loads per lane at a time)
+                            unsigned long long v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const uint32_t k = k0 + (uint32_t)u * 64u + lane;
+                                v[u] = k < grp ? __hip_atomic_load(lb_s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                e_ok = e_ok && (v[u] >> 32) == (tag >> 32);
+                                e_acc += v[u] & 0xFFFFFFFFull;
+                            }
+                        }
+                    }
+                    if (!in_done && __all((vi >> 32) == (tag >> 32))) {
+                        in_grp = wave_sum(vi & 0xFFFFFFFFull);
+                        in_done = true;
+                        if (r == kFinFan - 1 && lane == 0) { // the last of its 64 publishes their sum (a 64's frames fit 32 bits)
+                            const unsigned long long sum64 = in_grp + total;
+                            __hip_atomic_store(lb_s + grp, tag | (sum64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : sum64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    if (!e_done && __all(e_ok)) {
+                        earlier = wave_sum(e_acc);
+                        e_done = true;
+                    }
+                    if (!(in_done && e_done)) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > kLbSpinLimit) { failed = true; in_done = e_done = true; in_grp = earlier = 0; }
+                    }
+                } while (!(in_done && e_done));
+                before = in_grp + earlier;
             }
             if (__any(failed) && lane == 0) atomicOr(&a.hdr->retry, 4u); // gave up waiting: the host returns ADSB_E_STATE
             if (blk == n_blk - 1 && lane == 0) { // the last workgroup: the whole launch's total is known here
