@@ -1101,7 +1101,7 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
         // [phase:3 hand-over: slots, offsets, sliced bytes]
         // ---- phase 3: PPM slice of the gate survivors; the CRC stage is a kernel of its own --------------------
         // Every survivor gets a frame slot, its absolute offset and its 14 sliced bytes (the image is here, in
-        // LDS).  CRC-24, repair, ordering inside the tile and the valid-frame count are finish_candidates' work, one
+        // LDS).  CRC-24, repair, ordering inside the tile and the valid-frame count are finish_order's work, one
         // LANE per survivor instead of sixteen.  (With the whole decode in this kernel a tile's 33 KB of LDS were
         // held through a latency-bound epilogue: 19 % of the kernel time for 13 % of its instructions.)
         uint32_t total = misc[12];
@@ -1166,7 +1166,7 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
             }
         };
         if (simple) {
-            slice_round(base_slot, total); // unordered list (finish_candidates ranks it): survivor j -> slot j
+            slice_round(base_slot, total); // unordered list (finish_order ranks it): survivor j -> slot j
         } else {
             if (tid == 0) {
                 const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
@@ -1226,7 +1226,7 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
             e.cand = total;
             e.valid = misc[8];
             e.decoded = base_slot == kNoBase ? 1u : 0u;
-            p.seg[tile] = e; // (finish_candidates sums the groups' counters, this tile's count included)
+            p.seg[tile] = e; // (finish_order reads it)
         }
     }
     // [phase:end]

@@ -347,8 +347,8 @@ int adsb_debug_mag_mode(adsb_ctx *ctx);
  * slicer of the i8 path work on these; utils.rs:46-52's root is only taken where a comparison needs it).  0xFFFF marks
  * a sample whose two packing paths disagree.  ADSB_E_STATE for a CS16 context. */
 int adsb_debug_nsq_values(adsb_ctx *ctx, const void *iq_host, size_t n_samples, uint16_t *vals_host);
-/* Measurement only: with on != 0 the following launches run the scan kernel (squared magnitude + preamble/DF17
- * gate + slice of the survivors) and the ordering pass but not the finishing kernel -- no survivor is CRC-checked, so
+/* Measurement only: with on != 0 the following launches run the scan kernel (magnitude + preamble/DF17 gate + slice
+ * of the survivors) but not the finishing kernel -- no survivor is CRC-checked, the header reports an empty list, so
  * NO frames come out.  on = 0 restores the full path. */
 int adsb_debug_fused_pass_only(adsb_ctx *ctx, int on);
 /* Which scan kernel an i8 context launches: 1 = floor(sqrt) per sample (default), 0 = the A/B kernel whose gate

@@ -355,9 +355,9 @@ def test_16GiB_cs16_whole_buffer(gpu, oracle):
     torch.cuda.empty_cache()
 
 
-# ---- the opt-in mode that runs finish + gather on their own stream beside the next launch's scan ---------------------
+# ---- the opt-in mode that runs the finishing kernel on its own stream beside the next launch's scan ------------------
 def test_overlapped_small_kernels_mode_matches_oracle(gpu, oracle, monkeypatch):
-    """ADSB_OVERLAP_ORDERING=1 (read at adsb_create): finish_candidates and gather_tiles of launch k run on a second,
+    """ADSB_OVERLAP_ORDERING=1 (read at adsb_create): finish_order of launch k runs on a second,
     high-priority stream behind the scan's own completion event while the scan of launch k+1 already runs.  Three
     device-resident buffers are launched back to back, twice, with no host synchronisation in between; every launch's
     list must be the oracle's (result sets alternate: a missing dependency shows as a mixed or stale list)."""
