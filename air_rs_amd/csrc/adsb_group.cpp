@@ -228,6 +228,9 @@ static int merge_lists(adsb_group *g)
     }
     if (total > pos) flags |= ADSB_FLAG_TRUNCATED;
     GHIP(hipSetDevice(g->dev[g->root]));
+    // (the pinned header words below may still be the source of the previous merge's copy, which
+    // adsb_group_result_device does not wait for)
+    GHIP(hipStreamSynchronize(g->root_stream));
     for (const Part &p : parts) {
         const adsb_frame *src = nullptr;
         int rc = adsb_result_device(g->ctx[p.member], &src, nullptr);
