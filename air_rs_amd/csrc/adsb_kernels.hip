@@ -282,10 +282,23 @@ constexpr int kNsqPhys = (int)nsq_phys(kNsqLog);  // 8976 dwords = 35904 bytes
 static_assert(kNsqHalf % 64 == 0 && kHalo % 64 == 0 && kRun == 32 && (kNsqPadShift == 5 || kNsqPadShift == 6),
               "nsq image: pads every 32 or 64 dwords, runs of 32");
 
+// The u8 magnitude image of the i8 root scan, optionally padded (-DADSB_MAG_PAD=1): 16 bytes after every 256.  The gate's
+// ds_read_b128 has lane L start at byte 32 L: the sixteen lanes of a read group span 512 bytes, two passes over the 64
+// banks (lanes L and L + 8 on the same four banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.27 for the kernel).  With
+// the pad lanes 8-15 sit four banks further: conflict-free.  Physical byte = b + 16 (b >> 8).
+#ifndef ADSB_MAG_PAD
+#define ADSB_MAG_PAD 0
+#endif
+template <int ST, int SCAN> struct MagPad {
+    static constexpr bool on = ADSB_MAG_PAD != 0 && ST == ADSB_SAMPLE_I8 && SCAN == kScanRoot;
+};
+template <bool PAD> __host__ __device__ constexpr uint32_t mag_phys(uint32_t b) { return PAD ? b + 16u * (b >> 8) : b; }
+
 template <int ST, int SCAN = kScanRoot> struct Lds {
     typedef typename MagT<ST>::type mag_t;
     static constexpr bool kNsq = ST == ADSB_SAMPLE_I8 && SCAN == kScanNsq;
-    static constexpr int kMagBytes = kNsq ? kNsqPhys * 4 : TileCfg<ST>::kMagT * (int)sizeof(mag_t);
+    static constexpr int kMagBytes = kNsq ? kNsqPhys * 4
+                                          : (int)((mag_phys<MagPad<ST, SCAN>::on>((uint32_t)TileCfg<ST>::kMagT * (uint32_t)sizeof(mag_t)) + 15u) & ~15u);
     static constexpr int kOffCand = kMagBytes;                 // one word per run of 32 offsets: survivor bitmap
     static constexpr int kOffList = kOffCand + 2 * kThreads * 4 * ((TileCfg<ST>::kRunT + 31) / 32); // kListCap x u16
     static constexpr int kOffMisc = kOffList + kListCap * 2;   // 16 x u32
@@ -350,7 +363,7 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v)
 // [phase:3 slice_byte (helper; inlined twice)]
 // The PPM slice of one frame byte (demod.rs:92-131 + 180-201 in closed form): bit (7-k) = m[16 lb + 2k] > m[16 lb + 2k + 1]
 // over the magnitudes off+16+16*lb .. +15 of the tile in LDS; strict, a tie gives 0.
-template <int ST>
+template <int ST, bool PAD = false>
 __device__ __forceinline__ uint32_t slice_byte(const typename MagT<ST>::type *mag, const uint32_t off, const uint32_t lb)
 {
     uint32_t byte = 0;
@@ -363,7 +376,18 @@ __device__ __forceinline__ uint32_t slice_byte(const typename MagT<ST>::type *ma
         const uint32_t pidx = off + 16 + 16 * lb;
         const uint32_t *mw = reinterpret_cast<const uint32_t *>(mag) + (pidx >> 2);
         const uint32_t sh = pidx & 3;
-        uint32_t d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
+        uint32_t d0, d1, d2, d3, d4;
+        if constexpr (PAD) { // (the five dwords may lie either side of a pad: physical dword = d + 4 (d >> 6))
+            const uint32_t *m0 = reinterpret_cast<const uint32_t *>(mag);
+            const uint32_t di = pidx >> 2;
+            d0 = m0[di + 4u * (di >> 6)];
+            d1 = m0[di + 1u + 4u * ((di + 1u) >> 6)];
+            d2 = m0[di + 2u + 4u * ((di + 2u) >> 6)];
+            d3 = m0[di + 3u + 4u * ((di + 3u) >> 6)];
+            d4 = m0[di + 4u + 4u * ((di + 4u) >> 6)];
+        } else {
+            d0 = mw[0], d1 = mw[1], d2 = mw[2], d3 = mw[3], d4 = mw[4];
+        }
         uint32_t w[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                          __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
         // dword k = [a0, b0, a1, b1] holds pairs 2k and 2k+1, bit = (a > b), MSB first: one SDWA byte compare per
@@ -605,7 +629,7 @@ struct NoHook {
 };
 
 // [phase:2 gate: set-up]
-template <int ST, int GROUP, int RUN, int NT, int HOOK_AT = -1, class HOOK = NoHook, bool F16OK = (ST == ADSB_SAMPLE_I8)>
+template <int ST, int GROUP, int RUN, int NT, int HOOK_AT = -1, class HOOK = NoHook, bool F16OK = (ST == ADSB_SAMPLE_I8), bool PAD = false>
 __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, uint32_t *cand, uint16_t *list,
                                            uint32_t *count, const uint32_t tid, const uint32_t n_valid,
                                            HOOK hook = HOOK())
@@ -620,13 +644,19 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
     for (int k = 0; k < WPR; ++k) candA[k] = candB[k] = 0u;
     // (offsets at or beyond n_valid do not exist in the reference loop, adsb.rs:98: masked out in gate_collect)
     constexpr int kGran = (RUN + 26 + SPG - 1) / SPG + 1; // granules a run may touch
-    const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + tid * RUN);
-    const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + (tid + NT) * RUN);
+    static_assert(!PAD || (ST == ADSB_SAMPLE_I8 && RUN == 32 && (NT * RUN) % 256 == 0), "the padded image: u8 magnitudes, runs of 32 bytes");
+    // (padded image: a run starts at physical byte 32 k + 16 (k >> 3); its granules 2 and 3 lie behind the next pad for
+    // the last run of a 256-byte row, k % 8 == 7 -- the same lanes for both runs, NT being a multiple of 8: a second
+    // base pointer, no arithmetic per granule)
+    const u32x4 *ga = reinterpret_cast<const u32x4 *>(mag + mag_phys<PAD>(tid * RUN));
+    const u32x4 *gb = reinterpret_cast<const u32x4 *>(mag + mag_phys<PAD>((tid + NT) * RUN));
+    const uint32_t hop = PAD && (tid & 7u) == 7u ? 1u : 0u;
+    const u32x4 *ga2 = ga + hop, *gb2 = gb + hop;
     uint32_t ra[kGran * 4], rb[kGran * 4];
     constexpr int kAhead = 48 / SPG; // granules resident ahead of the current block
 #pragma unroll
     for (int g = 0; g < kAhead; ++g) {
-        u32x4 a = ga[g], b = gb[g];
+        u32x4 a = (PAD && g >= 2) ? ga2[g] : ga[g], b = (PAD && g >= 2) ? gb2[g] : gb[g];
         ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
         rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
     }
@@ -667,7 +697,7 @@ __device__ __forceinline__ void gate_phase(const typename MagT<ST>::type *mag, u
             if (o % SPG == 0) { // keep 48 samples resident ahead of the block that starts here
                 const int g = o / SPG + kAhead;
                 if (g * SPG < RUN + 26) {
-                    u32x4 a = ga[g], b = gb[g];
+                    u32x4 a = (PAD && g >= 2) ? ga2[g] : ga[g], b = (PAD && g >= 2) ? gb2[g] : gb[g];
                     ra[4 * g] = a.x; ra[4 * g + 1] = a.y; ra[4 * g + 2] = a.z; ra[4 * g + 3] = a.w;
                     rb[4 * g] = b.x; rb[4 * g + 1] = b.y; rb[4 * g + 2] = b.z; rb[4 * g + 3] = b.w;
                 }
@@ -768,7 +798,7 @@ __device__ __forceinline__ void issue_tile_loads(const DemodArgs &p, const TileP
 
 // raw IQ -> magnitudes in LDS (u8 for i8 input, u16 for i16).  Returns (wave-uniform, CS16 only) whether this wave saw
 // a magnitude that is not an ordered f16 bit pattern (>= 0x7C00 = 31744): the gate then takes its integer form.
-template <int ST, int MAGMODE>
+template <int ST, int MAGMODE, bool PAD = false>
 __device__ __forceinline__ bool magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIters], typename MagT<ST>::type *mag, uint32_t tid)
 {
     uint32_t mx = 0;
@@ -783,7 +813,10 @@ __device__ __forceinline__ bool magnitudes_to_lds(const u32x4 (&raw)[P1<ST>::kIt
                 mags4_i16(raw[it], lo, hi);
                 mx = pkmax(mx, pkmax(lo, hi)); // (samples past the channel end read as zero)
             }
-            if (s < (uint32_t)TileCfg<ST>::kMagT) *reinterpret_cast<uint2 *>(mag + s) = make_uint2(lo, hi);
+            // (padded image: s = it * 2048 + 8 tid, so s >> 8 = 8 it + (tid >> 5): the pad is a constant per sweep plus a
+            // per-lane term -- written out so that the sweep's part folds into the store's immediate offset)
+            const uint32_t sp = PAD ? s + 16u * (tid >> 5) + (uint32_t)it * (16u * (kThreads * P1<ST>::kSPL / 256)) : s;
+            if (s < (uint32_t)TileCfg<ST>::kMagT) *reinterpret_cast<uint2 *>(mag + sp) = make_uint2(lo, hi);
         }
     }
     return ST == ADSB_SAMPLE_I16 && __builtin_amdgcn_ballot_w64(((mx & 0xFFFFu) >= 0x7C00u) || ((mx >> 16) >= 0x7C00u)) != 0;
@@ -1064,7 +1097,7 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
         // ---- phase 1, second half: raw IQ -> the LDS image ---------------------------------------------------
         bool wave_big;
         if constexpr (NSQ) wave_big = nsq_image_to_lds(raw_a, raw_b, img, tid);
-        else wave_big = magnitudes_to_lds<ST, MAGMODE>(raw, mag, tid);
+        else wave_big = magnitudes_to_lds<ST, MAGMODE, MagPad<ST, SCAN>::on>(raw, mag, tid);
         if ((NSQ || ST == ADSB_SAMPLE_I16) && lane == 0) misc[4 + wave] = wave_big ? 1u : 0u; // (every wave writes its own word)
         TSTAMP(1); // phase 1 arithmetic
         __syncthreads();
@@ -1091,7 +1124,7 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
                 else gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, false>(mag, cand, list, &misc[12], tid, n_valid);
             }
         } else {
-            gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads>(mag, cand, list, &misc[12], tid, n_valid);
+            gate_phase<ST, ADSB_GATE_GROUP, TC::kRunT, kThreads, -1, NoHook, (ST == ADSB_SAMPLE_I8), MagPad<ST, SCAN>::on>(mag, cand, list, &misc[12], tid, n_valid);
         }
 #endif
         TSTAMP(3); // phase 2
@@ -1148,7 +1181,7 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
         const uint32_t g = tid >> 4, l = tid & 15;
         auto slice_one = [&](uint32_t off) {
             if constexpr (NSQ) return nsq_slice_byte(img, off, l);
-            else return slice_byte<ST>(mag, off, l < 14 ? l : 13);
+            else return slice_byte<ST, MagPad<ST, SCAN>::on>(mag, off, l < 14 ? l : 13);
         };
         auto slice_round = [&](uint32_t slot0, uint32_t ncl) {
             for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
