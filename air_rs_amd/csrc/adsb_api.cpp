@@ -118,10 +118,10 @@ struct adsb_ctx {
         if (e_ != hipSuccess) return (int)e_;      \
     } while (0)
 
-static uint32_t tiles_for(uint64_t n_samples, int sample_type)
+static uint32_t tiles_for(uint64_t n_samples, int sample_type, int scan)
 {
     if (n_samples <= (uint64_t)kWindow) return 0;
-    const uint64_t n_off = n_samples - kWindow, tile = (uint64_t)adsbk::tile_offsets(sample_type);
+    const uint64_t n_off = n_samples - kWindow, tile = (uint64_t)adsbk::tile_offsets_of(sample_type, scan);
     return (uint32_t)((n_off + tile - 1) / tile);
 }
 
@@ -203,10 +203,12 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     if (const char *sp = getenv("ADSB_SMALL_PATH")) c->sm.enabled = !(sp[0] == '0');
     if (const char *sc = getenv("ADSB_SCAN")) {
         if (strcmp(sc, "nsq") == 0) c->scan = adsbk::kScanNsq;
+        else if (strcmp(sc, "reg") == 0) c->scan = adsbk::kScanReg;
         else if (strcmp(sc, "root") == 0 || sc[0] == 0) c->scan = adsbk::kScanRoot;
         else { delete c; return ADSB_E_ARG; }
     }
-    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type) * cfg->max_channels;
+    if (cfg->sample_type != ADSB_SAMPLE_I8) c->scan = adsbk::kScanRoot; // (CS16 has one scan kernel)
+    uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type, c->scan) * cfg->max_channels;
     if (tiles == 0) tiles = 1;
     if (tiles * adsbk::kQuota + cfg->max_out + kTile > 0xFFFFFFF0ull) { delete c; return ADSB_E_CAPACITY; }
     c->n_tiles_max = (uint32_t)tiles;
@@ -376,7 +378,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     c->last_channels = n_channels;
     c->last_samples = n_samples;
     c->last_stride = channel_stride;
-    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type);
+    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type, c->scan);
     c->last_tiles = c->last_tpc * n_channels;
     c->last_base = c->stream_base;
     c->launched = true;
@@ -456,7 +458,7 @@ static int small_init(adsb_ctx *c)
 {
     if (c->sm.ready) return ADSB_OK;
     if (!c->sm.enabled) return ADSB_E_STATE;
-    const uint64_t tile = (uint64_t)adsbk::tile_offsets(c->cfg.sample_type);
+    const uint64_t tile = (uint64_t)adsbk::tile_offsets_of(c->cfg.sample_type, c->scan);
     c->sm.max_samples = std::min<uint64_t>(c->cfg.max_samples, tile * adsbk::kFinishTilesPerWg + kWindow);
     // a buffer of n samples has at most n - 240 frames (one per offset: SURVEY F8)
     c->sm.cap = (uint32_t)std::min<uint64_t>(c->cfg.max_out, c->sm.max_samples);
@@ -497,7 +499,7 @@ static int small_launch(adsb_ctx *c, const void *iq, size_t n_samples, uint64_t 
     c->last_channels = 1;
     c->last_samples = n_samples;
     c->last_stride = n_samples;
-    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type);
+    c->last_tpc = tiles_for(n_samples, c->cfg.sample_type, c->scan);
     c->last_tiles = c->last_tpc;
     c->last_base = c->stream_base;
     c->launched = true;

@@ -42,7 +42,15 @@ constexpr int kTileMax = kTile > 2 * kThreads * kRunI16 ? kTile : 2 * kThreads *
 //   kScanRoot: floor(sqrt(n)) per sample (v_sqrt_f32), u8 magnitudes in LDS -- the product's kernel
 //   kScanNsq : the gate runs on n = I^2+Q^2 (no root per sample; exact: DESIGN.md section 4.1b), 2 bytes of LDS per
 //              sample; the round-3 A/B kernel (fewer VALU slots, half the resident workgroups: slower)
-constexpr int kScanNsq = 0, kScanRoot = 1;
+constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2;
+//   kScanReg : the nsq gate from registers, no LDS image (every wave a chunk of 4032 offsets; window overlap by DPP from
+//              the neighbouring lane); tiles of 16128 offsets
+constexpr int kRegTile = 4 * 2 * 63 * 32; // offsets per tile of the register scan: four waves x 4032
+// offsets per tile of a context (the scan kind is fixed at adsb_create)
+constexpr int tile_offsets_of(int sample_type, int scan)
+{
+    return (sample_type == ADSB_SAMPLE_I8 && scan == kScanReg) ? kRegTile : tile_offsets(sample_type);
+}
 constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
 constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path
 constexpr int kWindow = 240;    // 16 + 112*2  (reference src/adsb.rs:98)

@@ -1040,6 +1040,12 @@ __device__ __forceinline__ void gate_phase_nsq(const uint32_t *img, uint32_t *ca
 #ifndef ADSB_SCAN_WAVES
 #define ADSB_SCAN_WAVES 4
 #endif
+#ifndef ADSB_REG_ABL
+#define ADSB_REG_ABL 0
+#endif
+#ifndef ADSB_REG_WAVES
+#define ADSB_REG_WAVES 5 // waves per SIMD the register scan's allocation is held to (86-96 VGPRs)
+#endif
 // The tile body: everything one workgroup does for one tile (`first` = it is the launch's first workgroup: it clears
 // the result header's flags).  smem: Lds<ST, SCAN>::kTotal bytes, 16-byte aligned.
 template <int ST, int MAGMODE, int SCAN>
@@ -1705,6 +1711,301 @@ hipError_t launch_finish(hipStream_t s, const FinishArgs &a, hipEvent_t e0, hipE
     return hipGetLastError();
 }
 
+// ---- the register scan (i8, kScanReg): the nsq gate without an LDS image -----------------------------------------------
+// The nsq scan needs 10 % fewer instructions than the root scan and loses, because its image
+// takes 2 bytes of LDS per sample and halves the resident workgroups.  Here the image never exists.  Every WAVE takes a
+// chunk of 4032 offsets on its own: lane L slides along run A = offsets 32 L .. 32 L + 31 and run B = run A + 2016, packed
+// in the halves of one VGPR as in the nsq scan.  The wave reads its chunk fully coalesced (lane i takes granule
+// i + 64 g), turns the granules round in a wave-private 4 KB of LDS so that every lane holds ITS OWN 32 + 32 samples, and
+// packs them into 32 VGPRs of v = I^2 + Q^2 + 72.  The 26 samples of window beyond a lane's run are its right
+// neighbour's first 26 values -- the same registers one lane up: ONE DPP move each (wave_shl:1), where an image costs a
+// store and a load per value and a workgroup barrier.  Lane 63 only supplies them (its run A is lane 0's run B, its run
+// B belongs to the next chunk): 63 of 64 lanes produce offsets.  No barrier between loads and gate, no per-sample root,
+// no unpacking: 128 (v) + 26 (DPP) + 312 (gate) VALU per 64 offsets where the root scan takes ~ 770, and 18 KB of LDS per
+// workgroup.  Survivors are sliced from the IQ bytes themselves (L2-hot), roots only for their 112 pairs.
+// A tile (= workgroup = Seg entry = 32 frame slots) is four chunks: 16128 offsets.
+constexpr int kRegB = 63 * 32, kRegChunk = 2 * kRegB;
+template <bool F16OK>
+__device__ __forceinline__ void reg_gate(const uint32_t (&N)[32], uint32_t &bitsA, uint32_t &bitsB)
+{
+    uint32_t NX[26];
+#pragma unroll
+    for (int j = 0; j < 26; ++j) NX[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)N[j], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+#define RN(j) ((j) < 32 ? N[(j) < 32 ? (j) : 0] : NX[(j) >= 32 ? (j) - 32 : 0])
+    uint32_t H2[32 + 8], W3[32 + 16], F[32 + 9];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) H2[j] = pkmin(RN(j), RN(j + 2));
+#pragma unroll
+    for (int j = 3; j < 13; ++j) W3[j] = pkmax3<F16OK>(RN(j), RN(j + 1), RN(j + 2));
+#pragma unroll
+    for (int j = 1; j < 8; ++j) F[j] = pkmax3<F16OK>(RN(j), W3[j + 2], RN(j + 5));
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+        W3[o + 13] = pkmax3<F16OK>(RN(o + 13), RN(o + 14), RN(o + 15));
+        F[o + 8] = pkmax3<F16OK>(RN(o + 8), W3[o + 10], RN(o + 13));
+        const uint32_t lo = pkmax3<F16OK>(F[o + 1], F[o + 8], W3[o + 13]);
+        H2[o + 7] = pkmin(RN(o + 7), RN(o + 9));
+        const uint32_t hi = pkmin(H2[o], H2[o + 7]);
+        const uint32_t t = nsq_band(hi);
+        const bool pa = (uint16_t)t >= (uint16_t)lo;
+        const bool pb = (t >> 16) >= (lo >> 16);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa | pb) != 0, 0)) {
+            const uint32_t dh = pkmin3<F16OK>(pkmin3<F16OK>(RN(o + 16), RN(o + 19), RN(o + 21)), RN(o + 23), RN(o + 24));
+            const uint32_t dl = pkmax3<F16OK>(pkmax3<F16OK>(RN(o + 17), RN(o + 18), RN(o + 20)), RN(o + 22), RN(o + 25));
+            const uint32_t t2 = nsq_band(dh);
+            bool sa = pa & ((uint16_t)t2 >= (uint16_t)dl);
+            bool sb = pb & ((t2 >> 16) >= (dl >> 16));
+            if (__builtin_amdgcn_ballot_w64(sa | sb) != 0) {
+                const bool ea = ((uint16_t)hi >= (uint16_t)lo) & ((uint16_t)dh >= (uint16_t)dl);
+                const bool eb = ((hi >> 16) >= (lo >> 16)) & ((dh >> 16) >= (dl >> 16));
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((sa & !ea) | (sb & !eb)) != 0, 0)) {
+                    const bool ra = nsq_root(hi & 0xFFFFu) >= nsq_root(lo & 0xFFFFu) && nsq_root(dh & 0xFFFFu) >= nsq_root(dl & 0xFFFFu);
+                    const bool rb = nsq_root(hi >> 16) >= nsq_root(lo >> 16) && nsq_root(dh >> 16) >= nsq_root(dl >> 16);
+                    sa = sa && (ea || ra);
+                    sb = sb && (eb || rb);
+                }
+                if (sa) bitsA |= 1u << o;
+                if (sb) bitsB |= 1u << o;
+            }
+        }
+    }
+#undef RN
+}
+
+// (wave-private staging in LDS: lane i wrote granule i + 64 g and gets the granules of its own run back, 4 L .. 4 L + 3;
+// the granule index is XOR-swizzled so that both the writes and the 64-byte-strided reads of a 16-lane group fall on
+// distinct banks.  Lines read with 64-byte strides straight from memory, 2 lanes per 128-byte line and instruction,
+// measured 0.174 ms per GiB against 0.168 this way and 0.156 for the coalesced read alone.)
+__device__ __forceinline__ uint32_t reg_swz(uint32_t q) { return q ^ ((q >> 4) & 3u); }
+__device__ __forceinline__ void reg_transpose(u32x4 *stage, const u32x4 (&in)[4], u32x4 (&out)[4], uint32_t lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) stage[reg_swz(lane + 64u * g)] = in[g];
+    // (same wave: LDS operations complete in order; no barrier)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = stage[reg_swz(4u * lane + k)];
+}
+
+static_assert(kRegTile == 4 * kRegChunk && kThreads == 256, "four waves, one chunk each");
+struct RegLds {
+#ifndef ADSB_REG_STAGE_BYTES
+#define ADSB_REG_STAGE_BYTES 4096
+#endif
+    static constexpr int kOffCand = 4 * ADSB_REG_STAGE_BYTES;   // wave-private staging: 4 KB per wave
+    static constexpr int kOffList = kOffCand + 2048;            // survivor bitmap: 504 words (offset 32 w + b = bit b of word w)
+    static constexpr int kOffMisc = kOffList + kListCap * 2;
+    static constexpr int kTotal = kOffMisc + 64;
+};
+
+// Frame byte l of the survivor at tile offset `off`, sliced from the IQ bytes (one lane per byte, 16 samples = 8 pairs
+// each; lanes 14/15 repeat byte 13).  The reference compares truncated roots (demod.rs:106 on utils.rs:46-52):
+// bit = floor(sqrt(x)) > floor(sqrt(y)) = (r * r > y), r = floor(sqrt(x)) -- r * r is the largest square <= x, so a
+// square lies in (y, x] exactly when r * r > y.  r = trunc(sqrtf(x + 0.5)) is exact for x <= 32768.
+__device__ __forceinline__ uint32_t reg_slice_byte(__amdgpu_buffer_rsrc_t rsrc, const uint32_t off, const uint32_t l)
+{
+    const uint32_t b = 2u * (off + 16u + 16u * (l < 14u ? l : 13u)); // byte of the lane's first sample in the tile
+    const uint32_t base = b & ~3u, sh = b & 3u;
+    uint32_t d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 4u * k, 0, 0);
+    uint32_t byte = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh); // [I_a, Q_a, I_b, Q_b]
+        const uint32_t na = (uint32_t)__builtin_amdgcn_sdot4((int)(w & 0xFFFFu), (int)w, 0, false);
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_sdot4((int)(w & 0xFFFF0000u), (int)w, 0, false);
+        const uint32_t r = (uint32_t)__builtin_amdgcn_sqrtf((float)na + 0.5f);
+        byte |= (r * r > nb ? 1u : 0u) << (7 - k);
+    }
+    return byte;
+}
+
+__device__ __forceinline__ void scan_tile_reg(const DemodArgs &p, const uint32_t tile, const bool first, unsigned char *smem)
+{
+    typedef RegLds L;
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + L::kOffCand);
+    uint16_t *list = reinterpret_cast<uint16_t *>(smem + L::kOffList);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const TilePos tp = tile_pos<kRegTile>(p, tile);
+    const uint64_t sample0 = tp.sample0;
+    const uint32_t n_valid = tp.n_valid;
+    __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<2, kRegTile + kHalo>(p, tp, true);
+    // ---- the chunk's samples: eight coalesced 16-byte loads per lane, all in flight -------------------------------------
+    u32x4 la[4], lb[4];
+    const uint32_t chunk_byte = __builtin_amdgcn_readfirstlane(wave) * (2u * kRegChunk);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        la[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u, chunk_byte + 1024u * g, ADSB_LOAD_AUX);
+        lb[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u, chunk_byte + 2u * kRegB + 1024u * g, ADSB_LOAD_AUX);
+    }
+    if (tid == 0 && first) {
+        p.hdr->retry = 0;
+        if (p.count_groups) { // first pass of a launch: the finishing kernel ORs this launch's flags in
+            p.hdr->flags = 0;
+            if (p.hdr_pub) p.hdr_pub[2] = 0;
+        }
+    }
+    if (tid == 0) {
+        misc[8] = 0;  // valid-frame counter
+        misc[12] = 0; // survivor counter
+    }
+    uint32_t bitsA = 0, bitsB = 0;
+    {
+        u32x4 ra[4], rb[4];
+        u32x4 *stage = reinterpret_cast<u32x4 *>(smem) + (ADSB_REG_STAGE_BYTES / 16) * wave;
+        reg_transpose(stage, la, ra, lane);
+        reg_transpose(stage, lb, rb, lane);
+        uint32_t N[32];
+        uint32_t lo = 0x7BFF7BFFu; // (the same detection of values that are no ordered f16 patterns as nsq_image_to_lds)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t d[8];
+            nsq_pack16(ra[g], rb[g], d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) N[8 * g + k] = d[k];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) lo = pkmin3<true>(lo, d[k], d[k + 1]);
+        }
+        const bool big = __builtin_amdgcn_ballot_w64(((lo & 0xFFFFu) >= 0x7C00u) || ((lo >> 16) >= 0x7C00u)) != 0; // (per wave)
+        if (!big) reg_gate<true>(N, bitsA, bitsB);
+        else reg_gate<false>(N, bitsA, bitsB);
+    }
+#if ADSB_REG_ABL == 2 // (measurement: loads + gate only, as the prototype)
+    if ((bitsA | bitsB) == 0x12345678u && n_valid == 7) misc[8] = 1;
+    return;
+#endif
+    // offsets that do not exist (adsb.rs:98: the channel's last 240 samples start no window), and lane 63
+    const uint32_t oa = wave * (uint32_t)kRegChunk + 32u * lane, ob = oa + (uint32_t)kRegB;
+    const uint32_t va = (lane < 63u && n_valid > oa) ? n_valid - oa : 0u, vb = (lane < 63u && n_valid > ob) ? n_valid - ob : 0u;
+    bitsA &= va >= 32u ? 0xFFFFFFFFu : ((1u << va) - 1u);
+    bitsB &= vb >= 32u ? 0xFFFFFFFFu : ((1u << vb) - 1u);
+    // the tile's survivor bitmap (read by the dense path only) and, unordered, its survivor list
+    if (lane < 63u) {
+        cand[wave * 126u + lane] = bitsA;
+        cand[wave * 126u + 63u + lane] = bitsB;
+    }
+    if (bitsA | bitsB) {
+        uint32_t pos = atomicAdd(&misc[12], (uint32_t)(__builtin_popcount(bitsA) + __builtin_popcount(bitsB)));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint32_t bits = k ? bitsB : bitsA;
+            const uint32_t o0 = k ? ob : oa;
+            while (bits) {
+                const uint32_t bpos = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (pos < (uint32_t)kSparseCap) list[pos] = (uint16_t)(o0 + bpos);
+                ++pos;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- hand-over: every survivor gets a frame slot, its absolute offset and its 14 sliced bytes (as scan_tile's phase 3) --
+    uint32_t total = p.fused_pass_only ? 0u : misc[12];
+#if ADSB_REG_ABL == 1 // (measurement: survivors counted, not handed over)
+    if (total != 0x7FFFFFFFu) total = 0;
+#endif
+    const bool dense = total > (uint32_t)kSparseCap;
+    u32x4 cw = {0, 0, 0, 0};
+    uint32_t cnt = 0, my_first = 0;
+    if (dense) { // ordered compaction of the bitmap by workgroup-wide prefix sums; words 4 tid .. 4 tid + 3 per thread
+        if (4 * tid < (uint32_t)(kRegTile / 32)) cw = reinterpret_cast<const u32x4 *>(cand)[tid];
+        cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) + __builtin_popcount(cw.w);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += t;
+        }
+        if (lane == 63) misc[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            uint32_t t = misc[w];
+            wbase += (w < (int)wave) ? t : 0u;
+            total += t;
+        }
+        my_first = wbase + incl - cnt;
+    }
+    const bool simple = !dense && total <= kQuota;
+    const uint64_t abs0 = sample0 + p.offset_base; // absolute offset of this tile's offset 0
+    uint32_t base_slot = tile * kQuota;
+    const uint32_t g = tid >> 4, l = tid & 15;
+    auto slice_round = [&](uint32_t slot0, uint32_t ncl) {
+        for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
+            if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a survivor
+            const uint32_t ci = r + g;
+            const bool have = ci < ncl; // uniform within the 16-lane group
+            const uint32_t off = have ? list[ci] : 0u;
+            const uint32_t byte = reg_slice_byte(rsrc, off, l);
+            if (have) {
+                unsigned char *rec = reinterpret_cast<unsigned char *>(p.slots + (size_t)slot0 + ci);
+                const uint64_t o64 = abs0 + off;
+                if (l < 14) rec[8 + l] = (unsigned char)byte;
+                else reinterpret_cast<uint32_t *>(rec)[l - 14] = l == 14 ? (uint32_t)o64 : (uint32_t)(o64 >> 32);
+            }
+        }
+    };
+    if (simple) {
+        slice_round(base_slot, total);
+    } else {
+        if (tid == 0) {
+            const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+            misc[9] = (!p.pool_off && b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
+        }
+        __syncthreads();
+        base_slot = misc[9];
+        for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+            if (dense && cnt) {
+                uint32_t idx = my_first;
+                const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t bits = words[k];
+                    while (bits) {
+                        const uint32_t bpos = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        if (idx >= chunk && idx < chunk + kListCap) list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + bpos);
+                        ++idx;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
+            if (base_slot != kNoBase) {
+                slice_round(base_slot + chunk, ncl);
+            } else { // the slot store is full: this tile's survivors are decoded here only to be counted
+                for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
+                    if (r + 4 * wave >= ncl) break;
+                    const uint32_t ci = r + g;
+                    const bool have = ci < ncl;
+                    const uint32_t off = have ? list[ci] : 0u;
+                    const bool valid = count_candidate(have, reg_slice_byte(rsrc, off, l), l, lane);
+                    if (valid && l == 0) atomicAdd(&misc[8], 1u);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        Seg e;
+        e.base = base_slot;
+        e.cand = total;
+        e.valid = misc[8];
+        e.decoded = base_slot == kNoBase ? 1u : 0u;
+        p.seg[tile] = e;
+    }
+}
+
+__global__ __launch_bounds__(kThreads, ADSB_REG_WAVES) void demod_tiles_reg(DemodArgs p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RegLds::kTotal];
+    scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+}
+
 // ---- small buffers: scan + finish in ONE dispatch, results straight into host memory --------------------------------------
 // A buffer of at most kFinTiles tiles (the reference's own buffers: 20 000 samples = 2 tiles, adsb.rs:77-79; an SDR's MTU-
 // sized reads, adsb.rs:59-64) is not worth three host calls per kernel and a copy each way: one workgroup per tile runs the
@@ -1716,10 +2017,11 @@ static_assert(kFinThreads == kThreads, "the small-buffer kernel runs both bodies
 template <int ST, int MAGMODE, int SCAN>
 __global__ __launch_bounds__(kThreads, 4) void demod_small(DemodArgs p, FinishArgs f, SmallArgs sm)
 {
-    constexpr int kScanBytes = Lds<ST, SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
+    constexpr int kScanBytes = SCAN == kScanReg ? RegLds::kTotal : Lds<ST, SCAN == kScanReg ? kScanRoot : SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kScanBytes > kFinBytes ? kScanBytes : kFinBytes];
     __shared__ uint32_t last_flag;
-    scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    if constexpr (SCAN == kScanReg) scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    else scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     // hand-off to whichever workgroup arrives last (cdna_hip_programming.md Guideline 16: every storing wave drains its
     // stores, the workgroup's barrier, one lane's agent-scope release, then the counter; the reader acquires)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1755,6 +2057,7 @@ hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, 
     dim3 grid(p.tile_count), block(kThreads);
     if (sample_type == ADSB_SAMPLE_I16) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I16, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanNsq) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanNsq>), grid, block, 0, s, p, f, sm);
+    else if (scan == kScanReg) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanReg>), grid, block, 0, s, p, f, sm);
     else if (mag_mode == 0) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
     else if (mag_mode == 1) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 1, kScanRoot>), grid, block, 0, s, p, f, sm);
     else hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 2, kScanRoot>), grid, block, 0, s, p, f, sm);
@@ -1805,6 +2108,10 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
     if (a.tile_count == 0) return hipSuccess;
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
         hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq>), dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
+        return hipGetLastError();
+    }
+    if (sample_type == ADSB_SAMPLE_I8 && scan == kScanReg) {
+        hipExtLaunchKernelGGL(demod_tiles_reg, dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);

@@ -151,9 +151,10 @@ class AdsbDemod:
 
     @property
     def scan(self):
-        """'root' (floor(sqrt) per sample: the product's scan kernel, and CS16's only one) or 'nsq' (the A/B kernel
-        whose gate works on I^2+Q^2: i8 contexts created with ADSB_SCAN=nsq in the environment)."""
-        return "root" if self._lib.adsb_debug_scan(self._h) == 1 else "nsq"
+        """Which scan kernel this context launches (fixed at adsb_create by ADSB_SCAN): 'root' (floor(sqrt) per sample,
+        u8 magnitudes in LDS; CS16's only one), 'nsq' (the gate on I^2+Q^2 over an LDS image) or 'reg' (the same gate
+        from registers, no image)."""
+        return {0: "nsq", 1: "root", 2: "reg"}[self._lib.adsb_debug_scan(self._h)]
 
     def pool_limit(self, on=True):
         """Test knob: the shared slot pool hands out nothing (tiles over their quota lose their slots)."""

@@ -103,9 +103,9 @@ def main():
     ap.add_argument("--channels", type=int, default=1,
                     help="split the per-GPU buffer into this many independent channels handled by ONE launch "
                          "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
-    ap.add_argument("--scan", choices=["default", "nsq", "root"], default="default",
-                    help="i8 scan kernel: root = floor(sqrt) per sample (the product's), nsq = the gate on I^2+Q^2 (the round-3 "
-                         "A/B kernel); default = the library's default (ADSB_SCAN in the environment is honoured)")
+    ap.add_argument("--scan", choices=["default", "nsq", "root", "reg"], default="default",
+                    help="i8 scan kernel: root = floor(sqrt) per sample (the product's), nsq = the gate on I^2+Q^2 over an LDS image, reg = the same gate from registers (round-3 "
+                         "A/B kernels); default = the library's default (ADSB_SCAN in the environment is honoured)")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the multi-rank frame-list gather even with one rank (testing)")
     args = ap.parse_args()

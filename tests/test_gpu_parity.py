@@ -10,11 +10,11 @@ import air_rs_amd as A
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["root", "nsq"], autouse=True)
+@pytest.fixture(scope="module", params=["root", "nsq", "reg"], autouse=True)
 def scan_kind(request):
-    """Every i8 test of this module runs once per i8 scan kernel: "root" (the product's: floor(sqrt) per sample) and
-    "nsq" (the round-3 A/B kernel whose gate works on I^2+Q^2 -- kept selectable, so it must stay bit-exact too).
-    ADSB_SCAN is read by adsb_create."""
+    """Every i8 test of this module runs once per i8 scan kernel: "root" (floor(sqrt) per sample, u8 magnitudes in LDS),
+    "nsq" (the gate on I^2+Q^2 over an LDS image) and "reg" (the same gate from registers: chunks of 4032 offsets per wave,
+    tiles of 16128) -- all selectable, so all must stay bit-exact.  ADSB_SCAN is read by adsb_create."""
     old = os.environ.get("ADSB_SCAN")
     os.environ["ADSB_SCAN"] = request.param
     yield request.param
@@ -89,8 +89,9 @@ def test_magnitude_i16(dem16, oracle):
     assert (dem16.magnitudes(iq) == oracle.get_magnitude(iq)).all()
 
 
-@pytest.mark.parametrize("n", [240, 241, 255, 271, 272, 1000, 8192 + 239, 8192 + 240, 8192 + 241, 16384 + 239, 16384 + 240,
-                               16384 + 241, 20000, 32768 + 239, 32768 + 240, 32768 + 241, 65536 + 240, 100003])
+@pytest.mark.parametrize("n", [240, 241, 255, 271, 272, 1000, 2016 + 239, 2016 + 241, 4032 + 240, 4032 + 241, 8192 + 239, 8192 + 240,
+                               8192 + 241, 16128 + 239, 16128 + 240, 16128 + 241, 16384 + 239, 16384 + 240, 16384 + 241, 20000,
+                               32256 + 240, 32256 + 241, 32768 + 239, 32768 + 240, 32768 + 241, 65536 + 240, 100003])
 def test_synthetic_sizes_i8(dem8, oracle, n):
     cfg = A.synth_default(seed=100 + n, slot_len=600)
     iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, n)

@@ -132,9 +132,9 @@ def test_small_buffer_path_equals_three_kernel_path(gpu, oracle, monkeypatch):
     and 32-tile edges, for i8 (both scan kernels) and CS16, incl. dense input (every offset a frame) and a capacity
     smaller than the frame count."""
     # (tile = 16384 offsets for i8, 8192 for CS16: the 32-tile edge of the one-dispatch path lies at both)
-    sizes = [241, 1000, 8192 + 240, 16384 + 240, 16384 + 241, 20000, 3 * 16384 + 777, 32 * 8192 + 240, 32 * 8192 + 241,
-             32 * 16384 + 240, 32 * 16384 + 241, 600_000]
-    for st, scan in ((A.ADSB_SAMPLE_I8, "root"), (A.ADSB_SAMPLE_I8, "nsq"), (A.ADSB_SAMPLE_I16, "root")):
+    sizes = [241, 1000, 8192 + 240, 16128 + 240, 16128 + 241, 16384 + 240, 16384 + 241, 20000, 3 * 16384 + 777, 32 * 8192 + 240,
+             32 * 8192 + 241, 32 * 16128 + 240, 32 * 16128 + 241, 32 * 16384 + 240, 32 * 16384 + 241, 600_000]
+    for st, scan in ((A.ADSB_SAMPLE_I8, "root"), (A.ADSB_SAMPLE_I8, "nsq"), (A.ADSB_SAMPLE_I8, "reg"), (A.ADSB_SAMPLE_I16, "root")):
         monkeypatch.setenv("ADSB_SCAN", scan)
         cfg = A.synth_default(seed=61, slot_len=500)
         if st == A.ADSB_SAMPLE_I16:
@@ -164,6 +164,9 @@ def test_scan_kernel_selection(gpu, monkeypatch):
     monkeypatch.setenv("ADSB_SCAN", "nsq")
     with A.AdsbDemod(max_samples=4096, max_out=16) as d:
         assert d.scan == "nsq"
+    monkeypatch.setenv("ADSB_SCAN", "reg")
+    with A.AdsbDemod(max_samples=4096, max_out=16) as d:
+        assert d.scan == "reg"
     monkeypatch.setenv("ADSB_SCAN", "stream")
     with pytest.raises(A.AdsbError) as e:
         A.AdsbDemod(max_samples=4096, max_out=16)

@@ -24,12 +24,15 @@ def make(st, max_samples, max_out, scan="root", small_path="1"):
 # buffers on (default) and off; and small frame capacities (dense inputs overflow the slot pool and are re-planned)
 ctx = {(A.ADSB_SAMPLE_I8, "root"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19),
        (A.ADSB_SAMPLE_I8, "nsq"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="nsq"),
+       (A.ADSB_SAMPLE_I8, "reg"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="reg"),
+       (A.ADSB_SAMPLE_I8, "reg-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="reg", small_path="0"),
        (A.ADSB_SAMPLE_I8, "root-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, small_path="0"),
        (A.ADSB_SAMPLE_I8, "nsq-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="nsq", small_path="0"),
        (A.ADSB_SAMPLE_I16, "root"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19),
        (A.ADSB_SAMPLE_I16, "root-3k"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19, small_path="0"),
        (A.ADSB_SAMPLE_I8, "small"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000),
        (A.ADSB_SAMPLE_I8, "small-nsq"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, scan="nsq"),
+       (A.ADSB_SAMPLE_I8, "small-reg"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, scan="reg"),
        (A.ADSB_SAMPLE_I8, "small-3k"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, small_path="0"),
        (A.ADSB_SAMPLE_I16, "small"): make(A.ADSB_SAMPLE_I16, 1 << 20, 3000)}
 t0 = time.time()
@@ -40,11 +43,11 @@ while time.time() - t0 < args.seconds:
         t_note = time.time()
         print(f"  ... {runs} buffers, {fails} mismatches after {t_note - t0:.0f} s", flush=True)
     st = A.ADSB_SAMPLE_I8 if rng.random() < 0.7 else A.ADSB_SAMPLE_I16
-    kern = str(rng.choice(["root", "nsq", "root-3k", "nsq-3k"])) if st == A.ADSB_SAMPLE_I8 else str(rng.choice(["root", "root-3k"]))
+    kern = str(rng.choice(["root", "nsq", "reg", "root-3k", "nsq-3k", "reg-3k"])) if st == A.ADSB_SAMPLE_I8 else str(rng.choice(["root", "root-3k"]))
     n = int(rng.choice([rng.integers(240, 4000), rng.integers(4000, 200000), rng.integers(200000, 3000000)]))
     dense = rng.random() < 0.06
     if dense:
-        kern = str(rng.choice(["small", "small-nsq", "small-3k"])) if st == A.ADSB_SAMPLE_I8 else "small"
+        kern = str(rng.choice(["small", "small-nsq", "small-reg", "small-3k"])) if st == A.ADSB_SAMPLE_I8 else "small"
         n = min(n, 1 << 20)
     cfg = A.synth_default(seed=int(rng.integers(1, 1 << 40)), slot_len=int(rng.choice([300, 600, 2000, 9000])))
     cfg.noise_div = int(rng.choice([3, 8, 18, 60, 200]))
