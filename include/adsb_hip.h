@@ -351,9 +351,10 @@ int adsb_debug_nsq_values(adsb_ctx *ctx, const void *iq_host, size_t n_samples, 
  * of the survivors) but not the finishing kernel -- no survivor is CRC-checked, the header reports an empty list, so
  * NO frames come out.  on = 0 restores the full path. */
 int adsb_debug_fused_pass_only(adsb_ctx *ctx, int on);
-/* Which scan kernel an i8 context launches: 1 = floor(sqrt) per sample (default), 0 = the A/B kernel whose gate
- * works on n = I^2+Q^2, selected by ADSB_SCAN=nsq in the environment at adsb_create (same results; DESIGN.md
- * section 5.3 has the measurements).  Always 1 for CS16 (one kernel). */
+/* Which scan kernel an i8 context launches: 1 = floor(sqrt) per sample (default); 0 = the A/B kernel whose gate
+ * works on n = I^2+Q^2 over an LDS image (ADSB_SCAN=nsq in the environment at adsb_create); 2 = the same gate from
+ * registers, no image (ADSB_SCAN=reg).  Same results; DESIGN.md section 5.3 has the measurements.  Always 1 for CS16
+ * (one kernel). */
 int adsb_debug_scan(adsb_ctx *ctx);
 /* Test knob: with on != 0 the shared slot pool of the following launches hands out nothing, so every tile with
  * more gate survivors than its own 32 slots loses them: the launch's list comes out with ADSB_FLAG_INCOMPLETE (for
