@@ -17,23 +17,6 @@ def _eq(got, want):
         assert bad.size == 0, (bad[:5], got[bad[:3]], want[bad[:3]])
 
 
-def test_group_plan_covers_every_offset_once():
-    for n in (240, 241, 247, 248, 1000, 20000, 3_000_017):
-        for world in (1, 2, 3, 8, 64):
-            sh = A.group_plan(n, world)
-            assert sum(s[2] for s in sh) == n - 240
-            pos = 0
-            for first, ns, noff in sh:
-                if noff == 0:
-                    assert ns == 0
-                    continue
-                assert first == pos and first % 8 == 0 and ns == noff + 240 and first + ns <= n
-                pos += noff
-    with pytest.raises(A.AdsbError) as e:
-        A.group_plan(239, 2)
-    assert e.value.code == A.ADSB_E_SHORT
-
-
 @pytest.mark.parametrize("st,total,world", [(A.ADSB_SAMPLE_I8, 3_000_017, 8), (A.ADSB_SAMPLE_I8, 700_001, 3),
                                             (A.ADSB_SAMPLE_I8, 500_000, 2), (A.ADSB_SAMPLE_I16, 1_200_003, 8)])
 def test_group_equals_single_context_and_oracle(gpu, oracle, st, total, world):
