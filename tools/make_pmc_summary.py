@@ -31,6 +31,8 @@ i8 = json.load(open(os.path.join(G, "r_pmc_summary_i8.json")))
 i16 = json.load(open(os.path.join(G, "r_pmc_summary_i16.json")))
 nsq_path = os.path.join(G, "r_pmc_summary_nsq.json")
 nsq = json.load(open(nsq_path)) if os.path.exists(nsq_path) else None
+reg_path = os.path.join(G, "r_pmc_summary_reg.json")
+reg = json.load(open(reg_path)) if os.path.exists(reg_path) else None
 old = json.load(open(os.path.join(P, "pmc_summary.json")))
 before = old.get("before_the_split") or {"note": "demod_tiles with the whole decode inside (round 1 .. mid round 2)",
                                          "i8": old.get("i8", {}).get("demod_tiles", {}).get("derived"),
@@ -55,6 +57,8 @@ new = {
     # the round-3 A/B kernel (ADSB_SCAN=nsq: gate on I^2+Q^2, no root per sample, 2 bytes of LDS per sample -> 4 workgroups
     # per CU instead of 8): fewer VALU slots, more waiting
     "i8_nsq_scan": ({"demod_tiles": {"derived": derived(nsq["demod_tiles"], 1 << 29, 2), "raw": nsq["demod_tiles"]}} if nsq else None),
+    # the register scan (ADSB_SCAN=reg: the same gate from registers, no LDS image)
+    "i8_reg_scan": ({"demod_tiles": {"derived": derived(reg["demod_tiles"], 1 << 29, 2), "raw": reg["demod_tiles"]}} if reg else None),
     "before_the_split": before,
     # the scan kernel's PMC rows as it was trimmed after the split (each measured by the same passes, one MI355X box each)
     "demod_tiles_i8_history": [
@@ -75,7 +79,7 @@ new = {
     ],
 }
 json.dump(new, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
-for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"),
+for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"), ("r_bench_reg.json", "bench_reg_scan.json"),
                  ("r_feed_bench.txt", "feed_bench.txt"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
                  ("r_bench_cs16_16g.json", "bench_cs16_16GiB.json"), ("r_bench_64ch.json", "bench_64_channels.json"),
                  ("r_kernel_stats.csv", "kernel_stats.csv"), ("r_kernel_stats_16g.csv", "kernel_stats_16GiB.csv")):
