@@ -178,6 +178,37 @@ extern "C" void adsb_destroy(adsb_ctx *c)
     delete c;
 }
 
+// The code scan's table through the device (adsbk::launch_code_probe): tab[n] = c(n) | th(n) << 8 for n = I^2+Q^2 in
+// 0 .. 32768, c = the 8-bit code the gate slides over, th = the code a "low" may reach while floor(sqrt) of a "high" n can still
+// be >= its own.  What the kernel relies on (adsb_kernels.hip, "the code scan"): c is monotone, stays below 0x7C (an
+// ordered f16 pattern in the high byte), and th(n) >= c(top(n)), top(n) = the largest n' with floor(sqrt(n')) = floor(sqrt(n)).
+// ADSB_E_STATE if the device disagrees (no fallback: adsb_create fails).
+static int code_table_check(adsb_ctx *c, uint16_t *tab)
+{
+    uint16_t *dev = nullptr;
+    if (hipMalloc((void **)&dev, 32769 * sizeof(uint16_t)) != hipSuccess) return ADSB_E_NOMEM;
+    hipError_t e = adsbk::launch_code_probe(c->stream, dev);
+    if (e == hipSuccess) e = hipMemcpyAsync(tab, dev, 32769 * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return (int)e;
+    uint32_t root = 0;
+    for (uint32_t n = 0; n <= 32768; ++n) {
+        while ((root + 1) * (root + 1) <= n) ++root;
+        const uint32_t top = std::min<uint32_t>((root + 1) * (root + 1) - 1, 32768);
+        const uint32_t code = tab[n] & 0xFFu, th = tab[n] >> 8, code_top = tab[top] & 0xFFu;
+        if (code >= 0x7Cu || (n && code < (tab[n - 1] & 0xFFu)) || th < code_top) return ADSB_E_STATE;
+    }
+    return ADSB_OK;
+}
+
+extern "C" int adsb_debug_code_table(adsb_ctx *c, uint16_t *out32769)
+{
+    if (!c || !out32769) return ADSB_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    return code_table_check(c, out32769);
+}
+
 extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
 {
     if (!cfg || !out_ctx) return ADSB_E_ARG;
@@ -201,10 +232,12 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     // sample: four workgroups per CU; 10 % fewer VALU slots, 12 % slower -- DESIGN.md section 5.3): ADSB_SCAN=nsq in
     // the environment at adsb_create selects it.
     if (const char *sp = getenv("ADSB_SMALL_PATH")) c->sm.enabled = !(sp[0] == '0');
+    c->scan = adsbk::kScanCode;
     if (const char *sc = getenv("ADSB_SCAN")) {
         if (strcmp(sc, "nsq") == 0) c->scan = adsbk::kScanNsq;
         else if (strcmp(sc, "reg") == 0) c->scan = adsbk::kScanReg;
-        else if (strcmp(sc, "root") == 0 || sc[0] == 0) c->scan = adsbk::kScanRoot;
+        else if (strcmp(sc, "root") == 0) c->scan = adsbk::kScanRoot;
+        else if (strcmp(sc, "code") == 0 || sc[0] == 0) c->scan = adsbk::kScanCode;
         else { delete c; return ADSB_E_ARG; }
     }
     if (cfg->sample_type != ADSB_SAMPLE_I8) c->scan = adsbk::kScanRoot; // (CS16 has one scan kernel)
@@ -276,6 +309,13 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         else if (probe[1] == want) c->mag_mode = 1;
         else c->mag_mode = 2;
         if (const char *force = getenv("ADSB_FORCE_MAG_MODE")) c->mag_mode = atoi(force) % 3;
+        if (c->scan == adsbk::kScanCode) {
+            // The code scan's gate is a SUPERSET test only if this device's conversion and f16 multiply-add behave as the
+            // kernel assumes: check it through the kernel's own instructions, for every n an i8 sample can give.
+            std::vector<uint16_t> tab(32769);
+            const int prc = code_table_check(c, tab.data());
+            if (prc != ADSB_OK) { fail(prc); break; }
+        }
         // cycle counters of diagnostic builds (-DADSB_TILE_STAMPS=1); zeros otherwise
         c->stamps_bytes = adsbk::tile_stamps_built() ? (size_t)c->n_tiles_max * 64 + 512 : 512;
         if (hipMalloc((void **)&c->stamps, c->stamps_bytes) != hipSuccess || hipMemsetAsync(c->stamps, 0, c->stamps_bytes, c->stream) != hipSuccess) { fail(ADSB_E_NOMEM); break; }

@@ -42,7 +42,10 @@ constexpr int kTileMax = kTile > 2 * kThreads * kRunI16 ? kTile : 2 * kThreads *
 //   kScanRoot: floor(sqrt(n)) per sample (v_sqrt_f32), u8 magnitudes in LDS -- the product's kernel
 //   kScanNsq : the gate runs on n = I^2+Q^2 (no root per sample; exact: DESIGN.md section 4.1b), 2 bytes of LDS per
 //              sample; the round-3 A/B kernel (fewer VALU slots, half the resident workgroups: slower)
-constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2;
+constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2, kScanCode = 3;
+//   kScanCode: the gate slides over an 8-bit LOG code of n = I^2+Q^2 (one quarter-rate v_cvt_pk_fp8_f32 per pair of samples
+//              instead of a root per sample); a superset test on codes, the few uncertain survivors are decided from the
+//              samples themselves (adsb_kernels.hip, "the code scan"): the product's kernel since round 4
 //   kScanReg : the nsq gate from registers, no LDS image (every wave a chunk of 4032 offsets; window overlap by DPP from
 //              the neighbouring lane); tiles of 16128 offsets
 constexpr int kRegTile = 4 * 2 * 63 * 32; // offsets per tile of the register scan: four waves x 4032
@@ -126,6 +129,8 @@ struct SmallArgs {
 //   0: truncates as is; 1: truncates once MODE.fp_round(f32) is set to round-toward-zero;
 //   2: rounds to nearest regardless -> subtract 0.5 first.
 hipError_t probe_cvt(hipStream_t s, uint32_t *dev_scratch4, uint32_t host_out[4]);
+// the code scan's arithmetic on every n = 0 .. 32768: out[n] = c(n) | byte1(S(c(n) << 8)) << 8 (device buffer of 32769 u16)
+hipError_t launch_code_probe(hipStream_t s, uint16_t *dev_out32769);
 
 // e0/e1: optional events recorded at the start / end of the dispatch itself (nullptr: none)
 // scan: kScanNsq / kScanRoot (i8 only; CS16 has one kernel)

@@ -1434,14 +1434,19 @@ __device__ __forceinline__ uint32_t finish_big_tile(const FinishArgs &a, const S
         const uint32_t nc = (e.cand - chunk) < 64u ? (e.cand - chunk) : 64u;
         uint32_t w[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
         if (lane < nc) load_record(a.slots + (size_t)e.base + chunk + lane, w);
-        const bool valid = finish_record(w, lane < nc, crc_tab, syn_sorted);
+        // (offset all ones: a survivor of the code gate that the samples themselves rejected -- no record)
+        const bool valid = finish_record(w, lane < nc && w[1] != 0xFFFFFFFFu, crc_tab, syn_sorted);
         uint32_t slot = lane;
         if (e.cand <= (uint32_t)kSparseCap) { // one chunk, unordered: rank by offset (wrap-safe: a tile spans < 2^15)
-            const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[0]);
-            const int32_t mine = (int32_t)(w[0] - ref);
+            // keys: offset relative to some record's (within 2^15 either way) for records; above them and distinct for rejected
+            // ones, so that every lane gets a slot of its own
+            const bool rec = lane < nc && w[1] != 0xFFFFFFFFu;
+            const unsigned long long rm = __ballot(rec);
+            const uint32_t ref = rm ? (uint32_t)__builtin_amdgcn_readlane((int)w[0], (int)__builtin_ctzll(rm)) : 0u;
+            const int32_t mine = rec ? (int32_t)(w[0] - ref) : (int32_t)(0x40000000u + lane);
             uint32_t below = 0;
             for (uint32_t k = 0; k < nc; ++k) {
-                const int32_t other = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)w[0], (int)k) - ref);
+                const int32_t other = (int32_t)__builtin_amdgcn_readlane((int)mine, (int)k);
                 below += other < mine ? 1u : 0u;
             }
             slot = below;
@@ -1503,11 +1508,14 @@ __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t
 #if ADSB_FIN_ABL == 2
         valid[p] = small_[p] && sub < e[p].cand && (w[p][2] & 1u) == 0;
 #else
-        valid[p] = finish_record(w[p], small_[p] && sub < e[p].cand, crc_tab, syn_sorted);
+        // (offset all ones: a survivor of the code gate that the samples themselves rejected -- no record)
+        valid[p] = finish_record(w[p], small_[p] && sub < e[p].cand && w[p][1] != 0xFFFFFFFFu, crc_tab, syn_sorted);
 #endif
         // place inside the tile: rank by offset among the valid frames of the 16-lane row.  A tile's offsets lie within
         // 2^15 of each other: relative to the row's first survivor they fit 16 bits (wrap-safe); bit 16 = does not count.
-        const uint32_t ref = (uint32_t)__shfl((int)w[p][0], (int)(lane & 48u), 64);
+        // (relative to the row's first RECORD: a rejected survivor's all-ones offset is no reference)
+        const uint32_t recs = (uint32_t)(__ballot(w[p][1] != 0xFFFFFFFFu) >> (16u * g)) & 0xFFFFu;
+        const uint32_t ref = (uint32_t)__shfl((int)w[p][0], (int)((lane & 48u) + (recs ? (uint32_t)__builtin_ctz(recs) : 0u)), 64);
         const uint32_t key = valid[p] ? ((w[p][0] - ref + 0x8000u) & 0xFFFFu) : 0x10000u;
         rank[p] = row_rank(key);
         const uint32_t cnt = (uint32_t)__builtin_popcount((uint32_t)(__ballot(valid[p]) >> (16u * g)) & 0xFFFFu);
@@ -2006,6 +2014,508 @@ __global__ __launch_bounds__(kThreads, ADSB_REG_WAVES) void demod_tiles_reg(Demo
     scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
 }
 
+// ---- the code scan (i8, kScanCode): the gate on an 8-bit LOG code of n = I^2 + Q^2, no root per sample --------------------
+// The root scan spends 3.5 of its 5.5 phase-1 issue slots per sample on floor(sqrt(n)) (v_sqrt_f32 alone holds the SIMD
+// for 8 cycles) and is VALU-issue-bound.  The gate (demod.rs:17-57) only ORDERS truncated roots, and every survivor is
+// checked again before it leaves the kernel, so the image the gate slides over may be any monotone 8-bit code c(n) as
+// long as the test on codes passes wherever the reference's test on floor(sqrt) passes (a SUPERSET test) and whatever
+// it lets through is decided exactly afterwards:
+//   * c(n) = e4m3((n + 16) / 128): one v_pk_fma_f32 + one v_cvt_pk_fp8_f32 per PAIR of samples (a quarter-rate
+//     conversion: 1 slot per sample where root + pack take 3.5).  Monotone in n; 8 codes per octave of n + 16.
+//   * the gate's values are 16-bit lanes [other sample's code | code << 8]: the code in the HIGH byte of an f16 bit
+//     pattern below 0x7C00, so v_pk_maximum3_f16 / v_pk_min_u16 order them by code (the low byte only breaks ties
+//     between equal codes and never reaches a decision: all compares are on byte 1 / byte 3).  An image dword holds the
+//     codes of samples 2q, 2q+1 of the tile's first half and of its second half: [A(2q), A(2q+1), B(2q), B(2q+1)] -- the
+//     dword as it is serves sample 2q+1 of a lane's two runs, shifted left by 8 bits sample 2q: half an unpacking
+//     instruction per step where the root image needs one v_perm.
+//   * floor(sqrt(hi)) >= floor(sqrt(lo)) holds exactly when lo <= top(hi), the largest n with hi's root.  On codes:
+//     c(lo) <= byte1(S(pattern(hi))) with S(x) = 1.5 x + 2^-7 in f16 ARITHMETIC on the pattern (one v_pk_fma_f16): the
+//     f16 value of a pattern grows like (n + 16)^2, so one multiply-add bends the slack the way 2 sqrt(n) needs -- wide
+//     (in codes) at low levels, one code at high ones.  That byte1(S(c(n) << 8)) >= c(top(n)) for EVERY n is checked on
+//     the device, through these very instructions, when a context is created (adsb_create fails otherwise), and again
+//     by tests/test_gpu_code_scan.py.
+//   * a survivor of the code gate is CERTAIN when the codes themselves are strictly ordered (then n is) in both groups,
+//     and a sliced bit is certain when c(x) > byte1(S(c(y))) (bit 1) or c(x) < c(y) (bit 0).  Anything else (0.6 per
+//     tile on the synthetic stream) is decided from the samples themselves: the 16-lane group re-reads its 240 samples
+//     (L2 / Infinity Cache; 480 bytes) and runs the reference's arithmetic -- floor(sqrt) by v_sqrt_f32 of n + 0.5 --
+//     on them.  A survivor that fails there leaves a record whose offset is all ones; finish_order skips it.
+// Everything downstream (slots, Seg, finish_order, the small-buffer kernel) is the root scan's.
+constexpr int kCodeHalf = kTile / 2;                    // samples in the half a lane's run A / run B slides over
+constexpr int kCodeLog = (kCodeHalf + kHalo) / 2;       // logical dwords of the image (two samples of each half per dword)
+// The gate's ds_read_b128 has lane L start at dword 16 L: lanes L, L+4, L+8, L+12 of a 16-lane read group fall on the same
+// banks (4-way).  -DADSB_CODE_PAD=1 puts 4 pad dwords after every 64 (conflict-free; the slicer then pays for the address
+// arithmetic): measured no faster (profiles/r04_ab_code_pad.txt) -- the LDS is 20 % busy either way.
+#ifndef ADSB_CODE_PAD
+#define ADSB_CODE_PAD 0
+#endif
+__host__ __device__ constexpr uint32_t code_phys(uint32_t q) { return ADSB_CODE_PAD ? q + 4u * (q >> 6) : q; }
+constexpr int kCodePhys = (int)code_phys(kCodeLog);
+constexpr int kCodeBias = 16;                           // c(n) = e4m3((n + kCodeBias) * 2^-kCodeShift)
+constexpr int kCodeShift = 7;
+constexpr uint32_t kCodeSlackMul = 0x3E003E00u;         // 1.5    (f16 x 2)
+constexpr uint32_t kCodeSlackAdd = 0x20002000u;         // 2^-7   (f16 x 2)
+static_assert(kRun == 32 && kThreads == 256 && kCodeHalf % (kThreads * 8) == 0 && kHalo == 256, "code scan geometry");
+
+struct CodeLds {
+    static constexpr int kOffCand = kCodePhys * 4;                 // survivor bitmap: word w = offsets 32 w .. 32 w + 31
+    static constexpr int kOffList = kOffCand + 2 * kThreads * 4;   // kListCap x u16
+    static constexpr int kOffMisc = kOffList + kListCap * 2;
+    static constexpr int kTotal = kOffMisc + 64;
+};
+static_assert(CodeLds::kTotal <= 20480, "eight workgroups per CU");
+
+// the threshold pattern of a pair of code patterns (see above): byte 1 / byte 3 of the result are what lows compare with
+__device__ __forceinline__ uint32_t code_slack(uint32_t x, uint32_t add = kCodeSlackAdd)
+{
+    const f16x2 r = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, x), __builtin_bit_cast(f16x2, kCodeSlackMul),
+                                              __builtin_bit_cast(f16x2, add));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t byte1(uint32_t x) { return (x >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t byte3(uint32_t x) { return x >> 24; }
+
+// (2^23 + n) as float bits (what the dot4 leaves) -> (n + kCodeBias) * 2^-kCodeShift, two samples per v_pk_fma_f32 (exact)
+__device__ __forceinline__ f32x2 code_arg(int n0, int n1)
+{
+    constexpr float s = 1.0f / (float)(1 << kCodeShift), t = ((float)kCodeBias - 8388608.0f) / (float)(1 << kCodeShift);
+    const f32x2 f = {__builtin_bit_cast(float, n0), __builtin_bit_cast(float, n1)};
+    return __builtin_elementwise_fma(f, (f32x2){s, s}, (f32x2){t, t});
+}
+
+// probe (adsb_create, tests): out[n] = c(n) | byte1(S(c(n) << 8)) << 8 for n = 0 .. 32768, through the scan's own code
+__global__ void code_probe_kernel(uint16_t *out)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n > 32768u) return;
+    const f32x2 x = code_arg((int)(0x4B000000u + n), (int)(0x4B000000u + n));
+    const uint32_t c = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(x.x, x.y, 0, false) & 0xFFu;
+    out[n] = (uint16_t)(c | (byte1(code_slack(c << 8)) << 8));
+}
+hipError_t launch_code_probe(hipStream_t s, uint16_t *dev_out32769)
+{
+    hipLaunchKernelGGL(code_probe_kernel, dim3(129), dim3(256), 0, s, dev_out32769);
+    return hipGetLastError();
+}
+
+// [phase:1 code (loads, dots, conversions, stores)]
+constexpr int kCodeFull = kCodeHalf / (kThreads * 8);   // sweeps every lane takes part in (4); one more covers the halo
+__device__ __forceinline__ void code_issue_loads(__amdgpu_buffer_rsrc_t rsrc, uint32_t tid, u32x4 (&ra)[kCodeFull + 1], u32x4 (&rb)[kCodeFull + 1])
+{
+    // (the sweep's constant goes into the SGPR offset, which the descriptor's bounds check covers; reads past the channel
+    // end return zeros)
+#pragma unroll
+    for (int it = 0; it < kCodeFull; ++it) {
+        ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16), ADSB_LOAD_AUX);
+        rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)it * (kThreads * 16) + 2 * kCodeHalf, ADSB_LOAD_AUX);
+    }
+    if (__builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kHalo) { // the halo: 256 samples of each half (wave 0, lanes 0-31)
+        ra[kCodeFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kCodeFull * (kThreads * 16), ADSB_LOAD_AUX);
+        rb[kCodeFull] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, (uint32_t)kCodeFull * (kThreads * 16) + 2 * kCodeHalf, ADSB_LOAD_AUX);
+    }
+}
+// 8 samples of the first half + the 8 samples half a tile further -> four image dwords
+__device__ __forceinline__ u32x4 code_pack16(u32x4 a, u32x4 b)
+{
+    int n[8];
+    uint32_t d[4];
+    dot4x8_sacc(a, 0x4B000000, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 x = code_arg(n[2 * j], n[2 * j + 1]);
+        // (asm: the builtin ties the destination -- the conversion keeps its other half -- and costs a v_mov per dword; that
+        // half is overwritten below, so whatever the register held will do)
+        asm("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(d[j]) : "v"(x.x), "v"(x.y));
+    }
+    dot4x8_sacc(b, 0x4B000000, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 x = code_arg(n[2 * j], n[2 * j + 1]);
+        d[j] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(x.x, x.y, (int)d[j], true);
+    }
+    return u32x4{d[0], d[1], d[2], d[3]};
+}
+__device__ __forceinline__ void code_image_to_lds(const u32x4 (&ra)[kCodeFull + 1], const u32x4 (&rb)[kCodeFull + 1], uint32_t *img, uint32_t tid)
+{
+    // logical dword of a lane's four in sweep `it`: it * 1024 + 4 tid; its pad 4 (it * 16 + (tid >> 4)): a constant per sweep
+    u32x4 *dst = reinterpret_cast<u32x4 *>(img + code_phys(4 * tid));
+#pragma unroll
+    for (int it = 0; it < kCodeFull; ++it) dst[(int)code_phys(it * kThreads * 4) / 4] = code_pack16(ra[it], rb[it]);
+    if (__builtin_amdgcn_readfirstlane(tid & ~63u) * 8 < (uint32_t)kHalo) {
+        const u32x4 d = code_pack16(ra[kCodeFull], rb[kCodeFull]);
+        if (tid * 8 < (uint32_t)kHalo) dst[(int)code_phys(kCodeFull * kThreads * 4) / 4] = d;
+    }
+}
+
+// [phase:2 code gate]
+// Preamble + DF17 superset test for the 2 x 32 offsets this lane owns: run A = offsets 32 tid + o, run B = kCodeHalf +
+// 32 tid + o.  Offsets that pass both groups on codes are OR-ed into the lane's words of the LDS bitmap (candA / candB).
+__device__ __forceinline__ void gate_phase_code(const uint32_t *img, uint32_t *candA, uint32_t *candB, const uint32_t tid)
+{
+    constexpr int RUN = kRun;
+    // (survivors are OR-ed straight into the lane's two bitmap words in LDS: accumulators in registers cost four copies
+    // per step at every join of the unrolled steps)
+    *candA = 0u;
+    *candB = 0u;
+    uint32_t slack_add = kCodeSlackAdd; // (VOP3P takes one scalar operand: the other constant lives in a VGPR, once)
+    asm volatile("" : "+v"(slack_add));
+    // logical dwords 16 tid + k, k < 29: this lane's 16 and the first 13 of the next lane's (which may lie behind a pad)
+    const u32x4 *g0 = reinterpret_cast<const u32x4 *>(img + code_phys(16 * tid));
+    const u32x4 *g1 = reinterpret_cast<const u32x4 *>(img + code_phys(16 * tid + 16));
+    constexpr int kGran = (RUN + 26 + 7) / 8; // granules of four dwords = eight samples of each run
+    constexpr int kAhead = 6;                 // 48 samples resident ahead of the current step
+    uint32_t W[kGran * 4];
+    auto fetch = [&](int g) {
+        const u32x4 x = g < 4 ? g0[g] : g1[g - 4];
+        W[4 * g] = x.x; W[4 * g + 1] = x.y; W[4 * g + 2] = x.z; W[4 * g + 3] = x.w;
+    };
+#pragma unroll
+    for (int g = 0; g < kAhead; ++g) fetch(g);
+    //   N[j]  the pair of code patterns of sample j  H2[j] = min(N[j], N[j+2])
+    //   W3[j] = max(N[j..j+2])                       F[j]  = max(N[j], W3[j+2], N[j+5])
+    // highs of offset o: min(H2[o], H2[o+7]);  lows: max(F[o+1], F[o+8], W3[o+13])
+    uint32_t N[RUN + 26], H2[RUN + 8], W3[RUN + 16], F[RUN + 9];
+#define ADSB_CODE_N(j) (((j) & 1) ? W[(j) >> 1] : (W[(j) >> 1] << 8))
+#pragma unroll
+    for (int k = 0; k < 25; ++k) N[k] = ADSB_CODE_N(k);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) H2[j] = pkmin(N[j], N[j + 2]);
+#pragma unroll
+    for (int j = 3; j < 13; ++j) W3[j] = pkmax3<true>(N[j], N[j + 1], N[j + 2]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) F[j] = pkmax3<true>(N[j], W3[j + 2], N[j + 5]);
+#pragma unroll
+    for (int o = 0; o < RUN; ++o) {
+        if (o % 8 == 0) {
+            const int g = o / 8 + kAhead;
+            if (g < kGran) fetch(g);
+        }
+        N[o + 25] = ADSB_CODE_N(o + 25);
+        W3[o + 13] = pkmax3<true>(N[o + 13], N[o + 14], N[o + 15]);
+        F[o + 8] = pkmax3<true>(N[o + 8], W3[o + 10], N[o + 13]);           // lows 8,10,11,12,13
+        const uint32_t lo = pkmax3<true>(F[o + 1], F[o + 8], W3[o + 13]);   // + 1,3,4,5,6 + 13,14,15
+        H2[o + 7] = pkmin(N[o + 7], N[o + 9]);
+        const uint32_t hi = pkmin(H2[o], H2[o + 7]);                        // highs 0,2,7,9
+        const uint32_t th = code_slack(hi, slack_add);
+        const bool pa = byte1(th) >= byte1(lo);
+        const bool pb = byte3(th) >= byte3(lo);
+        // wave-uniform tests (scalar branches): a block is entered by the whole wave when any lane needs it
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa | pb) != 0, 0)) {
+            // DF17 part of the gate (demod.rs:45-54), the same superset test
+            const uint32_t dh = pkmin3<true>(pkmin3<true>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
+            const uint32_t dl = pkmax3<true>(pkmax3<true>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
+            const uint32_t t2 = code_slack(dh, slack_add);
+            const bool sa = pa & (byte1(t2) >= byte1(dl));
+            const bool sb = pb & (byte3(t2) >= byte3(dl));
+            uint32_t bit = 1u << o;
+            asm("" : "+v"(bit)); // one v_mov for both stores
+            if (sa) atomicOr(candA, bit);
+            if (sb) atomicOr(candB, bit);
+        }
+    }
+#undef ADSB_CODE_N
+}
+
+// [phase:3 code slicer]
+// One survivor (tile offset `off`) by its 16-lane group, from the codes.  Lane l < 14: frame byte l -- bit = 1 where
+// c(x) > byte1(S(c(y))) (then floor(sqrt(x)) > floor(sqrt(y)): x lies above every n that shares y's root), 0 where
+// c(x) < c(y) (then x < y).  Lane 14 looks at the preamble's 16 samples, lane 15 at the ten DF17 samples: the gate's
+// verdict is CERTAIN where the codes themselves are strictly ordered (then n is).  Returns the lane's byte; `unc_mask` =
+// the wave's lanes that saw a pair / a group which is neither: the samples themselves decide (exact_from_raw).
+__device__ __forceinline__ uint32_t code_slice_byte(const uint32_t *img, const uint32_t off, const uint32_t l, unsigned long long &unc_mask)
+{
+    const uint32_t h = off >= (uint32_t)kCodeHalf ? 1u : 0u;
+    // the lane's first sample, counted inside its half: byte l's sixteen, the preamble's (lane 14), DF17's (lane 15)
+    const uint32_t s0 = off - h * (uint32_t)kCodeHalf + (l < 14u ? 16u + 16u * l : (l == 14u ? 0u : 16u));
+    const uint32_t e = s0 & 1u, q = s0 >> 1;
+    uint32_t D[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) D[i] = img[code_phys(q + (uint32_t)i)];
+    // [0, c(y), 0, c(x)] of the lane's pair k (x = its sample 2k, y = 2k+1) by one v_perm over dwords k, k+1 (selectors
+    // 0-3: 2nd operand, 4-7: 1st, 0x0C: zero): e = 0: bytes 2h, 2h+1 of dword k;  e = 1: byte 2h+1 of dword k, byte 2h of k+1
+    const uint32_t cx_sel = 2u * h + e, cy_sel = e ? 4u + 2u * h : 2u * h + 1u;
+    const uint32_t sel = 0x000C000Cu | (cy_sel << 8) | (cx_sel << 24);
+    uint32_t xy[8], t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        xy[k] = __builtin_amdgcn_perm(D[k + 1], D[k], sel);
+        t[k] = code_slack(xy[k]);
+    }
+    // bit k = c(x) > byte1(S(c(y))), MSB first: one SDWA compare per pair into its own SGPR pair, then byte = byte + byte +
+    // carry-in per pair (v_addc): no v_cndmask.  All eight compares come first: gfx950 wants 2 wait states between a VALU
+    // writing an SGPR and a VALU reading it, and hipcc pads nothing inside asm.
+    uint32_t byte = 0;
+    uint64_t m0, m1, m2, m3, m4, m5, m6, m7;
+    asm("v_cmp_gt_u32_sdwa %1, %9, %17 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %2, %10, %18 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %3, %11, %19 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %4, %12, %20 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %5, %13, %21 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %6, %14, %22 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %7, %15, %23 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_cmp_gt_u32_sdwa %8, %16, %24 src0_sel:BYTE_3 src1_sel:BYTE_1\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %4\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %5\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %6\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %7\n\t"
+        "v_addc_co_u32_e64 %0, vcc, %0, %0, %8"
+        : "+v"(byte), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+        : "v"(xy[0]), "v"(xy[1]), "v"(xy[2]), "v"(xy[3]), "v"(xy[4]), "v"(xy[5]), "v"(xy[6]), "v"(xy[7]),
+          "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7])
+        : "vcc");
+    // a pair is decided when bit 1 is certain (above) or c(x) < c(y); the lane masks stay in scalar registers
+    const uint64_t ms[8] = {m0, m1, m2, m3, m4, m5, m6, m7};
+    unsigned long long decided = ~0ull;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) decided &= ms[k] | __builtin_amdgcn_ballot_w64(byte3(xy[k]) < byte1(xy[k]));
+    // even samples sit in the high halves, odd ones in the low halves (patterns c << 8)
+    // preamble (demod.rs:20-22): highs 0, 2, 7, 9; lows the other twelve
+    const uint32_t p1 = pkmin(xy[0], xy[1]), p2 = pkmin(xy[3], xy[4]);                       // hi: {0, 2} | lo: {7, 9}
+    const uint32_t ma = pkmax3<true>(xy[2], xy[3], xy[4]), mb = pkmax3<true>(xy[5], xy[6], xy[7]); // hi: {4,6,8}, {10,12,14}
+    const uint32_t mc = pkmax3<true>(xy[0], xy[1], xy[2]);                                    // lo: {1,3,5}; mb lo: {11,13,15}
+    const uint32_t pre_hi = min(p1 >> 16, p2 & 0xFFFFu);
+    const uint32_t pre_lo = max(max(ma >> 16, mb >> 16), max(mc & 0xFFFFu, mb & 0xFFFFu));
+    // DF17 (demod.rs:41-44) on the lane's samples 0 .. 9: highs 0, 3, 5, 7, 8; lows 1, 2, 4, 6, 9
+    const uint32_t q1 = pkmin(xy[0], xy[4]), q2 = pkmin3<true>(xy[1], xy[2], xy[3]);         // hi: {0, 8} | lo: {3, 5, 7}
+    const uint32_t r1 = pkmax3<true>(xy[1], xy[2], xy[3]), r2 = pkmax(xy[0], xy[4]);         // hi: {2, 4, 6} | lo: {1, 9}
+    const uint32_t df_hi = min(q1 >> 16, q2 & 0xFFFFu), df_lo = max(r1 >> 16, r2 & 0xFFFFu);
+    const unsigned long long pre_ok = __builtin_amdgcn_ballot_w64(pre_hi > pre_lo), df_ok = __builtin_amdgcn_ballot_w64(df_hi > df_lo);
+    constexpr unsigned long long k14 = 0x4000400040004000ull, k15 = 0x8000800080008000ull; // lane 14 / 15 of every group
+    unc_mask = (~decided & ~(k14 | k15)) | (~pre_ok & k14) | (~df_ok & k15);
+    return byte;
+}
+
+// [phase:3 exact_from_raw (uncertain survivors only: cold)]
+// The reference's own arithmetic on a survivor's 240 samples, by its 16-lane group (ALL 16 lanes active): lane l < 14
+// takes frame byte l (samples off + 16 + 16 l .. + 15 of the tile), lane 14 the preamble (samples off .. off + 15), lane 15
+// repeats lane 14.  m = floor(sqrt(I^2+Q^2)) as utils.rs:46-52 (v_sqrt_f32 of n + 0.5, truncated: exact for n <= 32768).
+// Returns the lane's byte; gate_ok (group-uniform) = the preamble test on lane 14's magnitudes (demod.rs:23-36) and the
+// DF17 test on the first ten of lane 0's (demod.rs:45-54).
+__device__ __forceinline__ uint32_t exact_from_raw(__amdgpu_buffer_rsrc_t rsrc, const uint32_t off, const uint32_t l, const uint32_t lane, bool &gate_ok)
+{
+    const uint32_t s = off + (l < 14u ? 16u + 16u * l : 0u);
+    const uint32_t a = 2u * s, base = a & ~3u, sh = a & 3u; // (sh = 0 or 2)
+    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, 0, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + 16u, 0, 0);
+    const uint32_t v2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 32u, 0, 0);
+    const uint32_t d[9] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2};
+    uint32_t m[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh); // [I, Q, I', Q'] of samples 2k, 2k+1
+        const int n0 = __builtin_amdgcn_sdot4((int)(w & 0xFFFFu), (int)w, 0x4B000000, false);
+        const int n1 = __builtin_amdgcn_sdot4((int)(w & 0xFFFF0000u), (int)w, 0x4B000000, false);
+        m[2 * k] = (uint32_t)__builtin_amdgcn_sqrtf(__builtin_bit_cast(float, n0) - 8388607.5f);
+        m[2 * k + 1] = (uint32_t)__builtin_amdgcn_sqrtf(__builtin_bit_cast(float, n1) - 8388607.5f);
+    }
+    uint32_t byte = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) byte |= (m[2 * k] > m[2 * k + 1] ? 1u : 0u) << (7 - k);
+    auto mn = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+    auto mx = [](uint32_t x, uint32_t y) { return x > y ? x : y; };
+    const uint32_t hi = mn(mn(m[0], m[2]), mn(m[7], m[9]));
+    const uint32_t lo = mx(mx(mx(mx(m[1], m[3]), mx(m[4], m[5])), mx(mx(m[6], m[8]), mx(m[10], m[11]))), mx(mx(m[12], m[13]), mx(m[14], m[15])));
+    const uint32_t dh = mn(mn(mn(m[0], m[3]), mn(m[5], m[7])), m[8]);
+    const uint32_t dl = mx(mx(mx(m[1], m[2]), mx(m[4], m[6])), m[9]);
+    const unsigned long long pm = __builtin_amdgcn_ballot_w64(hi >= lo), dm = __builtin_amdgcn_ballot_w64(dh >= dl);
+    const uint32_t g0 = lane & 48u;
+    gate_ok = (((pm >> (g0 + 14u)) & (dm >> g0)) & 1ull) != 0;
+    return byte;
+}
+
+// [phase:end]
+__device__ __forceinline__ void scan_tile_code(const DemodArgs &p, const uint32_t tile, const bool first, unsigned char *smem)
+{
+    typedef CodeLds L;
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + L::kOffCand);
+    uint16_t *list = reinterpret_cast<uint16_t *>(smem + L::kOffList);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::kOffMisc);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const TilePos tp = tile_pos<kTile>(p, tile);
+    const uint64_t sample0 = tp.sample0;
+    const uint32_t n_valid = tp.n_valid;
+    __amdgpu_buffer_rsrc_t rsrc = tile_rsrc<2, kMag>(p, tp, true);
+    // [phase:1 code (loads, dots, conversions, stores)]
+    u32x4 ra[kCodeFull + 1], rb[kCodeFull + 1];
+    code_issue_loads(rsrc, tid, ra, rb);
+    if (tid == 0 && first) {
+        p.hdr->retry = 0;
+        if (p.count_groups) { // first pass of a launch: the finishing kernel ORs this launch's flags in
+            p.hdr->flags = 0;
+            if (p.hdr_pub) p.hdr_pub[2] = 0;
+        }
+    }
+    if (tid == 0) {
+        misc[8] = 0;  // valid-frame counter (tiles without slots only)
+        misc[12] = 0; // survivor counter
+    }
+    code_image_to_lds(ra, rb, img, tid);
+    __syncthreads();
+#if ADSB_ABL_PHASES < 2
+    if (smem[tid * 64] == 0xFD && smem[tid * 64 + 1] == 0xFE && n_valid == 7) misc[12] = 1;
+#else
+    // [phase:2 code gate]
+    gate_phase_code(img, cand + tid, cand + kThreads + tid, tid);
+    {
+        // (word w of the bitmap = offsets 32 w .. 32 w + 31: the lane's run A is word tid, its run B word kThreads + tid)
+        uint32_t bitsA = cand[tid], bitsB = cand[kThreads + tid];
+        const uint32_t oa = tid * (uint32_t)kRun, ob = oa + (uint32_t)kCodeHalf;
+        // offsets at or beyond n_valid do not exist in the reference loop (adsb.rs:98): the ragged last tile of a channel
+        if (n_valid < (uint32_t)kTile) { // (wave-uniform)
+            const uint32_t va = n_valid > oa ? n_valid - oa : 0u, vb = n_valid > ob ? n_valid - ob : 0u;
+            bitsA &= va >= 32u ? 0xFFFFFFFFu : ((1u << va) - 1u);
+            bitsB &= vb >= 32u ? 0xFFFFFFFFu : ((1u << vb) - 1u);
+            cand[tid] = bitsA; // (the dense path reads the bitmap itself)
+            cand[kThreads + tid] = bitsB;
+        }
+        // survivors are rare (a handful per tile): the few lanes that have any append their offsets, unordered, to the list
+        if (bitsA | bitsB) {
+            uint32_t pos = atomicAdd(&misc[12], (uint32_t)(__builtin_popcount(bitsA) + __builtin_popcount(bitsB)));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                uint32_t bits = k ? bitsB : bitsA;
+                const uint32_t o0 = k ? ob : oa;
+                while (bits) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if (pos < (uint32_t)kSparseCap) list[pos] = (uint16_t)(o0 + b);
+                    ++pos;
+                }
+            }
+        }
+    }
+#endif
+    __syncthreads();
+
+    // [phase:3 hand-over: slots, offsets, sliced bytes]
+    // Every survivor of the code gate gets a frame slot, its absolute offset and its 14 sliced bytes; one that the samples
+    // themselves reject gets an all-ones offset (finish_order skips it).  CRC-24, repair, ordering: finish_order.
+    uint32_t total = p.fused_pass_only ? 0u : misc[12];
+#if ADSB_ABL_PHASES < 3
+    if (total != 0x7FFFFFFFu) total = 0;
+#endif
+    const bool dense = total > (uint32_t)kSparseCap;
+    u32x4 cw = {0, 0, 0, 0};
+    uint32_t cnt = 0, my_first = 0;
+    if (dense) { // ordered compaction of the bitmap by workgroup-wide prefix sums; words 4 tid .. 4 tid + 3 per thread
+        if (4 * tid < (uint32_t)(kTile / 32)) cw = reinterpret_cast<const u32x4 *>(cand)[tid];
+        cnt = __builtin_popcount(cw.x) + __builtin_popcount(cw.y) + __builtin_popcount(cw.z) + __builtin_popcount(cw.w);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += t;
+        }
+        if (lane == 63) misc[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            uint32_t t = misc[w];
+            wbase += (w < (int)wave) ? t : 0u;
+            total += t;
+        }
+        my_first = wbase + incl - cnt;
+    }
+    const bool simple = !dense && total <= kQuota;
+    const uint64_t abs0 = sample0 + p.offset_base; // absolute offset of this tile's offset 0
+    uint32_t base_slot = tile * kQuota;
+    const uint32_t g = tid >> 4, l = tid & 15;
+    // one survivor per 16-lane group: its byte from the codes, or -- gate or some pair uncertain -- from the samples
+    auto slice_one = [&](const bool have, const uint32_t off, bool &dropped) {
+        unsigned long long um;
+        uint32_t byte = code_slice_byte(img, off, l, um);
+        um &= __builtin_amdgcn_ballot_w64(have);
+        const bool grp_unc = ((um >> (lane & 48u)) & 0xFFFFull) != 0;
+        dropped = false;
+        if (um != 0) { // (wave-uniform) some group of this wave needs the samples themselves
+            bool ok;
+            const uint32_t eb = exact_from_raw(rsrc, off, l, lane, ok);
+            if (grp_unc) {
+                byte = eb;
+                dropped = !ok;
+            }
+        }
+        return byte;
+    };
+    auto slice_round = [&](uint32_t slot0, uint32_t ncl) {
+        for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
+            if (r + 4 * wave >= ncl) break; // none of this wave's four groups has a survivor
+            const uint32_t ci = r + g;
+            const bool have = ci < ncl; // uniform within the 16-lane group
+            const uint32_t off = have ? list[ci] : 0u;
+            bool dropped;
+            const uint32_t byte = slice_one(have, off, dropped);
+            if (have) {
+                unsigned char *rec = reinterpret_cast<unsigned char *>(p.slots + (size_t)slot0 + ci);
+                const uint64_t o64 = dropped ? ~0ull : abs0 + off;
+                if (l < 14) rec[8 + l] = (unsigned char)byte;
+                else reinterpret_cast<uint32_t *>(rec)[l - 14] = l == 14 ? (uint32_t)o64 : (uint32_t)(o64 >> 32);
+            }
+        }
+    };
+    if (simple) {
+        slice_round(base_slot, total); // unordered list (finish_order ranks it): survivor j -> slot j
+    } else {
+        if (tid == 0) {
+            const unsigned long long b64 = atomicAdd(&p.hdr->alloc, (unsigned long long)total);
+            misc[9] = (!p.pool_off && b64 + total <= (unsigned long long)p.cap_slots) ? p.pool_first + (uint32_t)b64 : kNoBase;
+        }
+        __syncthreads();
+        base_slot = misc[9];
+        for (uint32_t chunk = 0; chunk < total; chunk += kListCap) {
+            if (dense && cnt) {
+                uint32_t idx = my_first;
+                const uint32_t words[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t bits = words[k];
+                    while (bits) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1;
+                        if (idx >= chunk && idx < chunk + kListCap) list[idx - chunk] = (uint16_t)((4 * tid + k) * 32 + b);
+                        ++idx;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t ncl = (total - chunk) < (uint32_t)kListCap ? (total - chunk) : (uint32_t)kListCap;
+            if (base_slot != kNoBase) {
+                slice_round(base_slot + chunk, ncl);
+            } else { // the slot store is full: this tile's survivors are decoded here only to be counted
+                for (uint32_t r = 0; r < ncl; r += kThreads / 16) {
+                    if (r + 4 * wave >= ncl) break;
+                    const uint32_t ci = r + g;
+                    const bool have = ci < ncl;
+                    const uint32_t off = have ? list[ci] : 0u;
+                    bool dropped;
+                    const uint32_t byte = slice_one(have, off, dropped);
+                    const bool valid = count_candidate(have && !dropped, byte, l, lane);
+                    if (valid && l == 0) atomicAdd(&misc[8], 1u);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        Seg e;
+        e.base = base_slot;
+        e.cand = total;
+        e.valid = misc[8];
+        e.decoded = base_slot == kNoBase ? 1u : 0u;
+        p.seg[tile] = e;
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 8) void demod_tiles_code(DemodArgs p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[CodeLds::kTotal];
+    scan_tile_code(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+}
+
 // ---- small buffers: scan + finish in ONE dispatch, results straight into host memory --------------------------------------
 // A buffer of at most kFinTiles tiles (the reference's own buffers: 20 000 samples = 2 tiles, adsb.rs:77-79; an SDR's MTU-
 // sized reads, adsb.rs:59-64) is not worth three host calls per kernel and a copy each way: one workgroup per tile runs the
@@ -2017,10 +2527,11 @@ static_assert(kFinThreads == kThreads, "the small-buffer kernel runs both bodies
 template <int ST, int MAGMODE, int SCAN>
 __global__ __launch_bounds__(kThreads, 4) void demod_small(DemodArgs p, FinishArgs f, SmallArgs sm)
 {
-    constexpr int kScanBytes = SCAN == kScanReg ? RegLds::kTotal : Lds<ST, SCAN == kScanReg ? kScanRoot : SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
+    constexpr int kScanBytes = SCAN == kScanReg ? RegLds::kTotal : SCAN == kScanCode ? CodeLds::kTotal : Lds<ST, (SCAN == kScanReg || SCAN == kScanCode) ? kScanRoot : SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kScanBytes > kFinBytes ? kScanBytes : kFinBytes];
     __shared__ uint32_t last_flag;
     if constexpr (SCAN == kScanReg) scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    else if constexpr (SCAN == kScanCode) scan_tile_code(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     else scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     // hand-off to whichever workgroup arrives last (cdna_hip_programming.md Guideline 16: every storing wave drains its
     // stores, the workgroup's barrier, one lane's agent-scope release, then the counter; the reader acquires)
@@ -2058,6 +2569,7 @@ hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, 
     if (sample_type == ADSB_SAMPLE_I16) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I16, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanNsq) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanNsq>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanReg) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanReg>), grid, block, 0, s, p, f, sm);
+    else if (scan == kScanCode) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanCode>), grid, block, 0, s, p, f, sm);
     else if (mag_mode == 0) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
     else if (mag_mode == 1) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 1, kScanRoot>), grid, block, 0, s, p, f, sm);
     else hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 2, kScanRoot>), grid, block, 0, s, p, f, sm);
@@ -2112,6 +2624,10 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
     }
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanReg) {
         hipExtLaunchKernelGGL(demod_tiles_reg, dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
+        return hipGetLastError();
+    }
+    if (sample_type == ADSB_SAMPLE_I8 && scan == kScanCode) {
+        hipExtLaunchKernelGGL(demod_tiles_code, dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);

@@ -151,10 +151,16 @@ class AdsbDemod:
 
     @property
     def scan(self):
-        """Which scan kernel this context launches (fixed at adsb_create by ADSB_SCAN): 'root' (floor(sqrt) per sample,
-        u8 magnitudes in LDS; CS16's only one), 'nsq' (the gate on I^2+Q^2 over an LDS image) or 'reg' (the same gate
-        from registers, no image)."""
-        return {0: "nsq", 1: "root", 2: "reg"}[self._lib.adsb_debug_scan(self._h)]
+        """Which scan kernel this context launches (fixed at adsb_create by ADSB_SCAN): 'code' (the default for i8: the gate
+        on an 8-bit log code of I^2+Q^2), 'root' (floor(sqrt) per sample, u8 magnitudes in LDS; CS16's only one), 'nsq' /
+        'reg' (the round-3 A/B kernels, in -DADSB_AB_KERNELS=1 builds only)."""
+        return {0: "nsq", 1: "root", 2: "reg", 3: "code"}[self._lib.adsb_debug_scan(self._h)]
+
+    def code_table(self):
+        """The code scan's table as the device computes it: uint16[32769], c(n) | th(n) << 8."""
+        out = np.empty(32769, dtype=np.uint16)
+        L.check(self._lib.adsb_debug_code_table(self._h, out.ctypes.data), "adsb_debug_code_table")
+        return out
 
     def pool_limit(self, on=True):
         """Test knob: the shared slot pool hands out nothing (tiles over their quota lose their slots)."""

@@ -24,6 +24,75 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PRESETS = {  # --preset NAME: the BASELINE.json configs by name (samples per GPU, extra flags)
+    "config2": {"samples": 1 << 29},                  # 1 GiB of i8 IQ on one GPU (the metric's workload; the default)
+    "config3": {"samples": 1 << 33},                  # 16 GiB of i8 IQ on one GPU
+    "config4": {"samples": 1 << 29, "channels": 64},  # 64 channels batched in one launch
+    "config5": {"samples": 1 << 33},                  # 8 GPUs x 16 GiB: run with --gpus 8
+}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--samples", type=int, default=None, help="IQ samples per GPU (2 B each for i8); default 2^29 = 1 GiB")
+    ap.add_argument("--preset", choices=sorted(PRESETS), default=None,
+                    help="a BASELINE.json config by name (sets --samples / --channels): config3 and config5 = 16 GiB per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-type", choices=["i8", "i16"], default="i8",
+                    help="i8 = BASELINE metric (2 B/sample); i16 = the reference's Complex<i16> (4 B/sample)")
+    ap.add_argument("--channels", type=int, default=None,
+                    help="split the per-GPU buffer into this many independent channels handled by ONE launch "
+                         "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
+    ap.add_argument("--scan", choices=["default", "code", "root", "nsq", "reg"], default="default",
+                    help="i8 scan kernel: code = the gate on an 8-bit log code of I^2+Q^2 (the product's since round 4), root = "
+                         "floor(sqrt) per sample (round 1-3's), nsq / reg = the round-3 A/B kernels (-DADSB_AB_KERNELS=1 builds "
+                         "only); default = the library's default (ADSB_SCAN in the environment is honoured)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="exercise the multi-rank frame-list gather even with one rank (testing)")
+    ap.add_argument("--no-feed", action="store_true", help="skip the PCIe-inclusive feed measurement after the timed region")
+    args = ap.parse_args(argv)
+    pre = PRESETS.get(args.preset, {})
+    if args.samples is None:
+        args.samples = pre.get("samples", 1 << 29)
+    if args.channels is None:
+        args.channels = pre.get("channels", 1)
+    return args
+
+
+def spawn_argv(argv, gpus, port):
+    """The command line of the child that runs `bench.py --gpus N` as N ranks (one per GPU) of ONE node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher environment: start the N ranks as a CHILD process (torch.distributed.run),
+    relay its stdout (rank 0's one JSON line) and exit code.  Nothing in this parent has touched HIP (torch and the library are
+    imported further down), and the child is a child, never an exec."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(spawn_argv(argv, args.gpus, port), env=env, stdout=subprocess.PIPE)
+    sys.stdout.buffer.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        sys.exit(self_launch(_a, sys.argv[1:]))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -92,23 +161,7 @@ def cpu_baseline(iq_host_i8, gpu_frames=None, target_seconds=15.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--samples", type=int, default=1 << 29, help="IQ samples per GPU (2 B each)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sample-type", choices=["i8", "i16"], default="i8",
-                    help="i8 = BASELINE metric (2 B/sample); i16 = the reference's Complex<i16> (4 B/sample)")
-    ap.add_argument("--channels", type=int, default=1,
-                    help="split the per-GPU buffer into this many independent channels handled by ONE launch "
-                         "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
-    ap.add_argument("--scan", choices=["default", "nsq", "root", "reg"], default="default",
-                    help="i8 scan kernel: root = floor(sqrt) per sample (the product's), nsq = the gate on I^2+Q^2 over an LDS image, reg = the same gate from registers (round-3 "
-                         "A/B kernels); default = the library's default (ADSB_SCAN in the environment is honoured)")
-    ap.add_argument("--force-gather", action="store_true",
-                    help="exercise the multi-rank frame-list gather even with one rank (testing)")
-    args = ap.parse_args()
+    args = parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a five-line version banner to fd 1 when the first
     # communicator comes up (native code, not Python): keep the real stdout aside for the JSON line and point
@@ -123,8 +176,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus N` by itself (it starts its own "
+                         "ranks) or under torch.distributed.run with --nproc-per-node N")
     # Rehearsal (ADSB_BENCH_REHEARSAL=1; tests/test_gpu_round2.py): N ranks SHARE GPU 0 -- RCCL refuses a communicator
     # with two ranks on one device, so the frame lists travel over gloo through pinned host memory.  Everything else
     # (shard plan, stream base, result targets in device buckets, rank-0 checks) is the N-GPU code; the throughput of
@@ -258,6 +311,15 @@ def main():
     if dist:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     frames_per_step = float(cnt.item())
+    # what the process group itself reports (a reader can see that N ranks took part) and every rank's own kernel times
+    ranks_seen = {"world_size": dist.get_world_size() if dist else 1, "backend": dist.get_backend() if dist else None,
+                  "launched_by": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "direct"}
+    mine = torch.tensor([demod_ms, decode_ms, float(local_rank)], dtype=torch.float64, device=red_dev)
+    per_rank = [mine]
+    if dist:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(x) for x in t.cpu()] for t in per_rank]
 
     if rank == 0:
         gather_check = None
@@ -337,6 +399,9 @@ def main():
             "frac_of_read_ceiling": round(achieved / ceil_gbps, 4) if ceil_gbps > 0 else None}
         if gather_check is not None:
             out["gather_check"] = gather_check
+        out["ranks_seen"] = ranks_seen
+        out["per_rank"] = {"scan_kernel_ms": [round(r[0], 4) for r in per_rank], "finish_order_ms": [round(r[1], 4) for r in per_rank],
+                           "device": [int(r[2]) for r in per_rank]}
         out["warmup_requested"] = args.warmup
         out["warmup_launches_total"] = warmup_total  # every untimed launch before the K timed ones (= "warmup")
         out["warmup_breakdown"] = {"cold_run_warmup": args.warmup, "cold_run_timed_steps": args.steps, "settle_launches": settle_launches,

@@ -10,7 +10,7 @@ import air_rs_amd as A
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["root", "nsq", "reg"], autouse=True)
+@pytest.fixture(scope="module", params=["code", "root", "nsq", "reg"], autouse=True)
 def scan_kind(request):
     """Every i8 test of this module runs once per i8 scan kernel: "root" (floor(sqrt) per sample, u8 magnitudes in LDS),
     "nsq" (the gate on I^2+Q^2 over an LDS image) and "reg" (the same gate from registers: chunks of 4032 offsets per wave,

@@ -23,7 +23,8 @@ import subprocess
 import sys
 import tempfile
 
-TRANS = ("v_sqrt_f32", "v_rsq_f32", "v_rcp_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32")
+TRANS = ("v_sqrt_f32", "v_rsq_f32", "v_rcp_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32",
+         "v_cvt_pk_fp8_f32", "v_cvt_pk_bf8_f32")  # (the fp8 conversions issue at the quarter rate too: profiles/r04_fp8_probe.txt)
 
 
 def phase_ranges(paths):
