@@ -232,12 +232,12 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
     // sample: four workgroups per CU; 10 % fewer VALU slots, 12 % slower -- DESIGN.md section 5.3): ADSB_SCAN=nsq in
     // the environment at adsb_create selects it.
     if (const char *sp = getenv("ADSB_SMALL_PATH")) c->sm.enabled = !(sp[0] == '0');
-    c->scan = adsbk::kScanCode;
+    c->scan = adsbk::kScanRoot;
     if (const char *sc = getenv("ADSB_SCAN")) {
         if (strcmp(sc, "nsq") == 0) c->scan = adsbk::kScanNsq;
         else if (strcmp(sc, "reg") == 0) c->scan = adsbk::kScanReg;
-        else if (strcmp(sc, "root") == 0) c->scan = adsbk::kScanRoot;
-        else if (strcmp(sc, "code") == 0 || sc[0] == 0) c->scan = adsbk::kScanCode;
+        else if (strcmp(sc, "root") == 0 || sc[0] == 0) c->scan = adsbk::kScanRoot;
+        else if (strcmp(sc, "code") == 0) c->scan = adsbk::kScanCode;
         else { delete c; return ADSB_E_ARG; }
     }
     if (cfg->sample_type != ADSB_SAMPLE_I8) c->scan = adsbk::kScanRoot; // (CS16 has one scan kernel)

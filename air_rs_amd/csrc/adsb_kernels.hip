@@ -2048,6 +2048,9 @@ constexpr int kCodeLog = (kCodeHalf + kHalo) / 2;       // logical dwords of the
 #ifndef ADSB_CODE_PAD
 #define ADSB_CODE_PAD 0
 #endif
+#ifndef ADSB_CODE_ABL
+#define ADSB_CODE_ABL 0
+#endif
 __host__ __device__ constexpr uint32_t code_phys(uint32_t q) { return ADSB_CODE_PAD ? q + 4u * (q >> 6) : q; }
 constexpr int kCodePhys = (int)code_phys(kCodeLog);
 constexpr int kCodeBias = 16;                           // c(n) = e4m3((n + kCodeBias) * 2^-kCodeShift)
@@ -2149,7 +2152,7 @@ __device__ __forceinline__ void code_image_to_lds(const u32x4 (&ra)[kCodeFull + 
 // [phase:2 code gate]
 // Preamble + DF17 superset test for the 2 x 32 offsets this lane owns: run A = offsets 32 tid + o, run B = kCodeHalf +
 // 32 tid + o.  Offsets that pass both groups on codes are OR-ed into the lane's words of the LDS bitmap (candA / candB).
-__device__ __forceinline__ void gate_phase_code(const uint32_t *img, uint32_t *candA, uint32_t *candB, const uint32_t tid)
+__device__ __forceinline__ void gate_phase_code(const uint32_t *img, uint32_t *candA, uint32_t *candB, const uint32_t tid, const uint32_t abl_key = 0)
 {
     constexpr int RUN = kRun;
     // (survivors are OR-ed straight into the lane's two bitmap words in LDS: accumulators in registers cost four copies
@@ -2199,7 +2202,11 @@ __device__ __forceinline__ void gate_phase_code(const uint32_t *img, uint32_t *c
         const bool pa = byte1(th) >= byte1(lo);
         const bool pb = byte3(th) >= byte3(lo);
         // wave-uniform tests (scalar branches): a block is entered by the whole wave when any lane needs it
+#if ADSB_CODE_ABL == 1 // (measurement only, wrong results: the hot path alone -- the cold block is never entered)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64((pa | pb) && abl_key == 7u) != 0, 0)) { // (n_valid == 7: never)
+#else
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa | pb) != 0, 0)) {
+#endif
             // DF17 part of the gate (demod.rs:45-54), the same superset test
             const uint32_t dh = pkmin3<true>(pkmin3<true>(N[o + 16], N[o + 19], N[o + 21]), N[o + 23], N[o + 24]);
             const uint32_t dl = pkmax3<true>(pkmax3<true>(N[o + 17], N[o + 18], N[o + 20]), N[o + 22], N[o + 25]);
@@ -2357,7 +2364,7 @@ __device__ __forceinline__ void scan_tile_code(const DemodArgs &p, const uint32_
     if (smem[tid * 64] == 0xFD && smem[tid * 64 + 1] == 0xFE && n_valid == 7) misc[12] = 1;
 #else
     // [phase:2 code gate]
-    gate_phase_code(img, cand + tid, cand + kThreads + tid, tid);
+    gate_phase_code(img, cand + tid, cand + kThreads + tid, tid, n_valid);
     {
         // (word w of the bitmap = offsets 32 w .. 32 w + 31: the lane's run A is word tid, its run B word kThreads + tid)
         uint32_t bitsA = cand[tid], bitsB = cand[kThreads + tid];
