@@ -92,6 +92,7 @@ struct adsb_ctx {
         uint64_t max_samples = 0;    // longest buffer the path takes
     } sm;
     bool pool_off = false;          // adsb_debug_pool_limit: the shared slot pool hands out nothing (test knob)
+    uint32_t stall_blk = 0xFFFFFFFFu; // adsb_debug_finish_stall: this workgroup of finish_order withholds its exchange word (test knob)
     uint32_t cap_slots = 0;
     uint32_t n_tiles_max = 0;
 
@@ -335,6 +336,25 @@ extern "C" int adsb_debug_fused_pass_only(adsb_ctx *c, int on)
 }
 extern "C" int adsb_debug_mag_mode(adsb_ctx *c) { return c ? c->mag_mode : ADSB_E_ARG; }
 extern "C" int adsb_debug_scan(adsb_ctx *c) { return c ? (c->cfg.sample_type == ADSB_SAMPLE_I8 ? c->scan : adsbk::kScanRoot) : ADSB_E_ARG; }
+// Test knobs.  adsb_debug_set_launch_index: the next launch counts as launch number `idx` (the exchange words' epoch is
+// derived from it: lets a test cross the 2^30 wrap).  adsb_debug_finish_stall: finish_order's workgroup `blk` of the
+// following launches withholds its exchange word (0xFFFFFFFF: none) -- the workgroups behind it give up after ~0.1 s.
+extern "C" int adsb_debug_set_launch_index(adsb_ctx *c, uint32_t idx)
+{
+    if (!c) return ADSB_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->own_aux) HIPCHK(hipStreamSynchronize(c->aux));
+    c->launch_idx = idx;
+    return ADSB_OK;
+}
+extern "C" int adsb_debug_finish_stall(adsb_ctx *c, uint32_t blk)
+{
+    if (!c) return ADSB_E_ARG;
+    c->stall_blk = blk;
+    return ADSB_OK;
+}
+
 extern "C" int adsb_debug_pool_limit(adsb_ctx *c, int on)
 {
     if (!c) return ADSB_E_ARG;
@@ -400,7 +420,18 @@ static adsbk::FinishArgs finish_args(adsb_ctx *c, adsb_ctx::ResultSet &r, uint32
     a.tile_first = tile_first;
     a.tile_count = tile_count;
     a.hdr = r.hdr;
+    a.stall_blk = rerun ? 0xFFFFFFFFu : c->stall_blk;
     return a;
+}
+
+// finish_order's exchange words are never cleared: they carry the launch's 30-bit epoch ((launch index + 1) mod 2^30) and a
+// word of another epoch reads as "not there yet".  A word written exactly 2^30 launches ago would read as this launch's:
+// whenever the epoch wraps (every ~4 hours of back-to-back 13 us launches) the words are zeroed on the stream first.
+static hipError_t clear_exchange_words_at_wrap(adsb_ctx *c, uint32_t launch_idx)
+{
+    if (((launch_idx + 1u) & 0x3FFFFFFFu) != 0u) return hipSuccess;
+    const size_t lb_words = (size_t)c->lb_groups_at + c->lb_groups_at / 64 + 64;
+    return hipMemsetAsync(c->lb, 0, sizeof(uint64_t) * lb_words, c->aux);
 }
 
 extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t n_channels,
@@ -430,6 +461,7 @@ extern "C" int adsb_demod_device_async(adsb_ctx *c, const void *iq_dev, uint32_t
     const uint32_t i = c->launch_idx;
     adsb_ctx::ResultSet &r = c->rs[i & 1u];
     if (c->own_aux && r.g_pending) HIPCHK(hipStreamWaitEvent(c->stream, r.g_done, 0));
+    HIPCHK(clear_exchange_words_at_wrap(c, i));
 
     hipEvent_t *ev = nullptr;
     if (c->timing && (c->launch_idx % (uint32_t)c->timing) == 0) {
@@ -547,6 +579,7 @@ static int small_launch(adsb_ctx *c, const void *iq, size_t n_samples, uint64_t 
     c->trk_done = false;
     const uint32_t i = c->launch_idx, set = i & 1u;
     adsb_ctx::ResultSet &r = c->rs[set];
+    HIPCHK(clear_exchange_words_at_wrap(c, i));
     adsbk::DemodArgs da = demod_args(c, r, 0, c->last_tiles, true);
     da.hdr_pub = reinterpret_cast<uint64_t *>(c->sm.blob[set]);
     adsbk::FinishArgs fa = finish_args(c, r, i, 0, c->last_tiles, false);
@@ -570,14 +603,17 @@ static int small_launch(adsb_ctx *c, const void *iq, size_t n_samples, uint64_t 
 }
 
 // Waits (polling pinned memory, no HIP call on the usual path) until result set `set` carries sequence number `seq`.
-static int small_wait(adsb_ctx *c, uint32_t set, uint64_t seq)
+// (at_least: a LATER launch on the same result set has finished -- the stream is in order -- will do as well: used where
+// only "the device no longer reads that launch's input" matters)
+static int small_wait(adsb_ctx *c, uint32_t set, uint64_t seq, bool at_least = false)
 {
     volatile uint64_t *w = small_seq_word(c, set);
-    for (uint32_t spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != seq; ++spins) {
+    auto done = [&]() { const uint64_t v = __atomic_load_n(w, __ATOMIC_ACQUIRE); return at_least ? v >= seq : v == seq; };
+    for (uint32_t spins = 0; !done(); ++spins) {
         if (spins > (1u << 22)) { // ~ tens of milliseconds of polling: let the runtime tell what happened
             HIPCHK(hipSetDevice(c->cfg.device));
             HIPCHK(hipStreamSynchronize(c->stream));
-            if (__atomic_load_n(w, __ATOMIC_ACQUIRE) != seq) return ADSB_E_STATE;
+            if (!done()) return ADSB_E_STATE;
             break;
         }
 #if defined(__x86_64__)
@@ -1092,6 +1128,10 @@ struct adsb_feed {
     std::vector<char *> ring;
     std::vector<hipEvent_t> ring_done; // H2D out of that ring slot has completed
     std::vector<char> ring_busy;
+    // a one-dispatch launch reads its samples straight from the ring slot: the slot may be overwritten once the launch's
+    // sequence word says so (ring_seq != 0: result set ring_set carries that number when the kernel has finished)
+    std::vector<uint64_t> ring_seq;
+    std::vector<uint32_t> ring_set;
     uint32_t ring_next = 0;
     int acquired = -1;
     uint64_t pushed = 0, popped = 0; // buffers
@@ -1161,6 +1201,8 @@ extern "C" int adsb_feed_open(adsb_ctx *c, const adsb_feed_cfg *cfg, adsb_feed *
         if (p) f->ring.push_back(p);
         if (e) f->ring_done.push_back(e);
         f->ring_busy.push_back(0);
+        f->ring_seq.push_back(0);
+        f->ring_set.push_back(0);
     }
     ok = ok && hipHostMalloc((void **)&f->hdr_host, sizeof(adsbk::Header), hipHostMallocDefault) == hipSuccess;
     if (!ok) { adsb_feed_close(f); return ADSB_E_NOMEM; }
@@ -1192,6 +1234,11 @@ static int feed_ring_slot(adsb_feed *f, uint32_t *slot)
     if (f->ring_busy[r]) { // the DMA out of this slot must have finished before the host overwrites it
         HIPCHK(hipEventSynchronize(f->ring_done[r]));
         f->ring_busy[r] = 0;
+    }
+    if (f->ring_seq[r]) { // ... and so must the one-dispatch kernel that reads its samples from the slot itself
+        const int rc = small_wait(f->c, f->ring_set[r], f->ring_seq[r], true);
+        if (rc != ADSB_OK) return rc;
+        f->ring_seq[r] = 0;
     }
     *slot = r;
     return ADSB_OK;
@@ -1255,7 +1302,9 @@ extern "C" int adsb_feed_push(adsb_feed *f, const void *iq_host, size_t n)
         e.launched = true;
         e.small = true;
         e.set = c->last;
-        f->ring_busy[r] = 0; // (the slot is not reused before this buffer has been popped: two in flight, >= 2 slots)
+        f->ring_busy[r] = 0;
+        f->ring_seq[r] = e.seq; // the kernel reads the slot until its sequence word is out (feed_ring_slot waits for it)
+        f->ring_set[r] = e.set;
         f->prev_host = start;
         f->prev_ring = r;
         f->prev_start = 0;

@@ -49,8 +49,16 @@ struct adsb_group {
     uint32_t flags = 0;
 };
 
+// The group calls switch the calling thread's current HIP device (every member lives on its own): they put it back.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 extern "C" void adsb_group_destroy(adsb_group *g)
 {
+    DeviceGuard restore_device;
     if (!g) return;
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         (void)hipSetDevice(g->dev[i]);
@@ -91,6 +99,7 @@ extern "C" int adsb_group_plan(uint64_t n_samples, uint32_t n_members, adsb_grou
 
 extern "C" int adsb_group_create(const adsb_group_cfg *cfg, adsb_group **out)
 {
+    DeviceGuard restore_device;
     if (!cfg || !out) return ADSB_E_ARG;
     *out = nullptr;
     if (cfg->abi_version != ADSB_ABI_VERSION || cfg->n_members == 0 || cfg->n_members > 64 || !cfg->devices ||
@@ -163,6 +172,7 @@ extern "C" adsb_ctx *adsb_group_member(adsb_group *g, uint32_t i) { return (g &&
 
 extern "C" int adsb_group_demod_device_async(adsb_group *g, const void *const *iq_dev, size_t n_samples)
 {
+    DeviceGuard restore_device;
     if (!g || !iq_dev) return ADSB_E_ARG;
     if (n_samples < kWindow) return ADSB_E_SHORT;
     if (n_samples > g->max_samples) return ADSB_E_CAPACITY;
@@ -184,6 +194,7 @@ extern "C" int adsb_group_demod_device_async(adsb_group *g, const void *const *i
 
 extern "C" int adsb_group_demod_host_async(adsb_group *g, const void *iq_host, size_t n_samples)
 {
+    DeviceGuard restore_device;
     if (!g || !iq_host) return ADSB_E_ARG;
     if (n_samples < kWindow) return ADSB_E_SHORT;
     if (n_samples > g->max_samples) return ADSB_E_CAPACITY;
@@ -195,8 +206,9 @@ extern "C" int adsb_group_demod_host_async(adsb_group *g, const void *iq_host, s
         if (plan[i].n_samples == 0) continue;
         if (!g->staging[i]) return ADSB_E_STATE; // created without host_staging
         GHIP(hipSetDevice(g->dev[i]));
-        // each member's slice travels on its own stream, in front of its own kernels: the copies of different
-        // devices overlap each other and the kernels of the members that already have their samples
+        // each member's slice travels on its own stream, in front of its own kernels.  With PINNED iq_host (hipHostMalloc /
+        // hipHostRegister by the caller) the copies of different devices overlap each other and the kernels of the members
+        // that already have their samples; from pageable memory the runtime stages them and they run one after the other
         GHIP(hipMemcpyAsync(g->staging[i], static_cast<const char *>(iq_host) + plan[i].first_sample * g->bps,
                             (size_t)plan[i].n_samples * g->bps, hipMemcpyHostToDevice, (hipStream_t)adsb_stream(g->ctx[i])));
         ptr[i] = g->staging[i];
@@ -253,6 +265,7 @@ static int merge_lists(adsb_group *g)
 
 extern "C" int adsb_group_result_device(adsb_group *g, const void **blob_dev, void **stream)
 {
+    DeviceGuard restore_device;
     if (!g) return ADSB_E_ARG;
     int rc = merge_lists(g);
     if (rc != ADSB_OK) return rc;
@@ -264,6 +277,7 @@ extern "C" int adsb_group_result_device(adsb_group *g, const void **blob_dev, vo
 extern "C" int adsb_group_fetch(adsb_group *g, adsb_frame *out, size_t max_out, size_t *n_out, uint64_t *total_found,
                                 uint32_t *flags)
 {
+    DeviceGuard restore_device;
     if (!g || !n_out || (!out && max_out)) return ADSB_E_ARG;
     *n_out = 0;
     int rc = merge_lists(g);

@@ -116,6 +116,7 @@ struct FinishArgs {
     uint32_t tile_first, tile_count;
     Header *hdr;
     uint64_t *hdr_pub;         // optional caller-owned copy of {n_out, total_found, flags} (4 x u64)
+    uint32_t stall_blk;        // test knob (adsb_debug_finish_stall): this workgroup withholds its exchange word; 0xFFFFFFFF: none
 };
 
 // demod_small: the one-dispatch path for buffers of at most kFinishTilesPerWg tiles

@@ -1462,6 +1462,10 @@ __device__ __forceinline__ uint32_t finish_big_tile(const FinishArgs &a, const S
 #endif
 constexpr int kFinLdsWords = 256 + 128 + 2 * kFinTiles; // tables, per-tile counts, per-tile positions
 // What workgroup `blk` of `n_blk` does (lds: kFinLdsWords words).
+// PUB_ATOMIC: the caller-owned header copy's flags word is updated with 64-bit atomic ORs (device memory: finish_order).  The
+// small-buffer kernel, whose copy lives in pinned HOST memory, passes false and publishes the flags itself with one plain
+// store at the end (atomics over PCIe are a platform option, not a given).
+template <bool PUB_ATOMIC = true>
 __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t blk, const uint32_t n_blk, uint32_t *lds)
 {
     uint32_t *crc_tab = lds, *syn_sorted = lds + 256;
@@ -1552,7 +1556,7 @@ __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t
         if (a.out_start == nullptr && ADSB_FIN_ABL != 1) {
             const unsigned long long tag = ((unsigned long long)a.epoch << 34) | ((unsigned long long)kLbReady << 32);
             uint64_t *lb_a = a.lb, *lb_s = a.lb + a.lb_groups_at; // one word per workgroup | one per 64 workgroups
-            if (lane == 0) __hip_atomic_store(lb_a + blk, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && blk != a.stall_blk) __hip_atomic_store(lb_a + blk, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t grp = blk / kFinFan, r = blk % kFinFan;
             bool failed = false;
             auto wave_sum = [&](unsigned long long x) {
@@ -1636,7 +1640,11 @@ __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t
                 } while (!(in_done && e_done));
                 before = in_grp + earlier;
             }
-            if (__any(failed) && lane == 0) atomicOr(&a.hdr->retry, 4u); // gave up waiting: the host returns ADSB_E_STATE
+            if (__any(failed) && lane == 0) { // gave up waiting: the host returns ADSB_E_STATE; device-side consumers see a list with holes
+                atomicOr(&a.hdr->retry, 4u);
+                atomicOr(&a.hdr->flags, ADSB_FLAG_INCOMPLETE);
+                if (PUB_ATOMIC && a.hdr_pub) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_INCOMPLETE);
+            }
             if (blk == n_blk - 1 && lane == 0) { // the last workgroup: the whole launch's total is known here
                 const unsigned long long tot = before + total, n_out = tot < a.max_out ? tot : a.max_out;
                 a.hdr->total_found = tot;
@@ -1647,7 +1655,7 @@ __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t
                 if (a.hdr_pub) {
                     a.hdr_pub[0] = n_out;
                     a.hdr_pub[1] = tot;
-                    if (tot > a.max_out) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_TRUNCATED);
+                    if (PUB_ATOMIC && tot > a.max_out) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_TRUNCATED);
                     a.hdr_pub[3] = 0;
                 }
                 if (a.chan_prefix) a.chan_prefix[a.n_channels] = tot;
@@ -1679,7 +1687,7 @@ __device__ __forceinline__ void finish_block(const FinishArgs &a, const uint32_t
             if (e[p].base == kNoBase && e[p].cand != 0 && counts[idx] != 0 && tpos[idx] < a.max_out && a.out_start == nullptr) {
                 atomicOr(&a.hdr->retry, 1u);
                 atomicOr(&a.hdr->flags, ADSB_FLAG_INCOMPLETE); // visible to device-side consumers: the list has holes
-                if (a.hdr_pub) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_INCOMPLETE);
+                if (PUB_ATOMIC && a.hdr_pub) atomicOr(reinterpret_cast<unsigned long long *>(a.hdr_pub + 2), (unsigned long long)ADSB_FLAG_INCOMPLETE);
             }
         }
     }
@@ -1708,7 +1716,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_order(FinishArgs a)
     if (a.max_out != 0xFFFFFFF1u) return;
 #endif
     __shared__ uint32_t lds[kFinLdsWords];
-    finish_block(a, blockIdx.x, gridDim.x, lds);
+    finish_block<true>(a, blockIdx.x, gridDim.x, lds);
 }
 
 hipError_t launch_finish(hipStream_t s, const FinishArgs &a, hipEvent_t e0, hipEvent_t e1)
@@ -2556,11 +2564,13 @@ __global__ __launch_bounds__(kThreads, 4) void demod_small(DemodArgs p, FinishAr
     }
     __syncthreads();
     if (!last_flag) return;
-    finish_block(f, 0, 1, reinterpret_cast<uint32_t *>(smem));
+    finish_block<false>(f, 0, 1, reinterpret_cast<uint32_t *>(smem));
     // everything is written (list and header, through f.out / f.hdr_pub): tell the host
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        // the flags this workgroup's lanes OR-ed into the device header, to the host copy by ONE plain store
+        if (f.hdr_pub) f.hdr_pub[2] = (uint64_t)__hip_atomic_load(&f.hdr->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *sm.done = 0; // re-armed for the next launch on this result set
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope: the host reads what this kernel wrote
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -90,7 +90,7 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
         tx.drop();
         return st;
     }
-    bool closed = false;
+    bool closed = false, pop_failed = false;
     // one finished buffer: AdsbPacket::new per frame, in order (adsb.rs:107-111)
     auto pop_and_send = [&]() {
         size_t n_out = 0;
@@ -100,6 +100,7 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
         if (prc != ADSB_OK) {
             if (st.last_error == ADSB_OK) st.last_error = prc;
             std::fprintf(stderr, "adsb_feed_pop failed: %s\n", adsb_strerror(prc));
+            pop_failed = true; // (that buffer's frames are gone: any error ends the thread, like a closed channel)
             return false;
         }
         if (flags & ADSB_FLAG_TRUNCATED) st.truncated_buffers++;
@@ -148,9 +149,9 @@ Thread2Stats process_sdr_data_thread(adsb_ctx *ctx, Receiver<std::vector<Complex
         st.buffers++;
         while (!closed && (adsb_feed_in_flight(feed) == 2 || (adsb_feed_in_flight(feed) > 0 && adsb_feed_ready(feed) == 1)))
             if (!pop_and_send()) break;
-        if (closed) break;
+        if (closed || pop_failed) break;
     }
-    while (!closed && adsb_feed_in_flight(feed) > 0)
+    while (!closed && !pop_failed && adsb_feed_in_flight(feed) > 0)
         if (!pop_and_send()) break;
     adsb_feed_close(feed);
     if (closed) return st;

@@ -162,6 +162,14 @@ class AdsbDemod:
         L.check(self._lib.adsb_debug_code_table(self._h, out.ctypes.data), "adsb_debug_code_table")
         return out
 
+    def set_launch_index(self, idx):
+        """Test knob: the next launch counts as launch number idx (epoch of finish_order's exchange words)."""
+        L.check(self._lib.adsb_debug_set_launch_index(self._h, int(idx) & 0xFFFFFFFF), "adsb_debug_set_launch_index")
+
+    def finish_stall(self, blk=0xFFFFFFFF):
+        """Test knob: finish_order's workgroup blk withholds its exchange word (default: none does)."""
+        L.check(self._lib.adsb_debug_finish_stall(self._h, int(blk) & 0xFFFFFFFF), "adsb_debug_finish_stall")
+
     def pool_limit(self, on=True):
         """Test knob: the shared slot pool hands out nothing (tiles over their quota lose their slots)."""
         L.check(self._lib.adsb_debug_pool_limit(self._h, 1 if on else 0), "adsb_debug_pool_limit")

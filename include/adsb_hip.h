@@ -364,6 +364,14 @@ int adsb_debug_code_table(adsb_ctx *ctx, uint16_t *out32769);
  * more gate survivors than its own 32 slots loses them: the launch's list comes out with ADSB_FLAG_INCOMPLETE (for
  * device-side consumers) and the host entry points take their re-run path -- deterministically. */
 int adsb_debug_pool_limit(adsb_ctx *ctx, int on);
+/* Test knob: the next launch counts as launch number `idx`.  finish_order tags its exchange words with the launch's epoch
+ * ((index + 1) mod 2^30) and the library zeroes them whenever the epoch wraps: this lets a test cross the wrap. */
+int adsb_debug_set_launch_index(adsb_ctx *ctx, uint32_t idx);
+/* Test knob: workgroup `blk` of finish_order withholds its exchange word in the following launches (0xFFFFFFFF: none).
+ * The workgroups behind it give up after ~0.1 s: adsb_fetch / adsb_fetch_counts return ADSB_E_STATE, the header carries
+ * ADSB_FLAG_INCOMPLETE, nothing hangs, and the context stays usable (the reference's only failure mode is a closed
+ * channel, src/adsb.rs:108-111: the replacement must not add a hang). */
+int adsb_debug_finish_stall(adsb_ctx *ctx, uint32_t blk);
 /* Diagnostic builds of demod_tiles (-DADSB_TILE_STAMPS=1) only: 16 uint32 per tile of the last launch (waves 0
  * and 3 of the tile's workgroup, 8 each: shader cycles in prologue, phase 1, barrier, phase 2, barrier, phase 3,
  * wait for the loads; s_memrealtime at start).  ADSB_E_STATE in a normal build. */
