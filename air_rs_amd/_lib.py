@@ -155,6 +155,8 @@ PROTOTYPES = {
     "adsb_debug_nsq_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "adsb_debug_scan": (C.c_int, [C.c_void_p]),
     "adsb_debug_code_table": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adsb_measure_feed": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_double, _P(C.c_double), _P(C.c_double), _P(C.c_uint64)]),
+    "adsb_measure_pinned_copy": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _P(C.c_double)]),
     "adsb_debug_set_launch_index": (C.c_int, [C.c_void_p, C.c_uint32]),
     "adsb_debug_finish_stall": (C.c_int, [C.c_void_p, C.c_uint32]),
     "adsb_debug_pool_limit": (C.c_int, [C.c_void_p, C.c_int]),

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -978,6 +979,121 @@ extern "C" int adsb_time_read_ceiling(adsb_ctx *c, const void *buf_dev, size_t b
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_per_pass = (double)ms / iters;
+    return ADSB_OK;
+}
+
+// ---- measurement: the host-fed (PCIe-inclusive) rate of the streaming front end ---------------------------------------------
+// What the reference's thread 1 -> thread 2 hand-over costs per buffer through adsb_feed_* (src/adsb.rs:75-89: playback
+// sends 20 000-sample buffers; adsb.rs:59-64: MTU-sized reads), measured from C (no interpreter in the loop): a context
+// and a feed of its own on `device`, synthetic samples written into the pinned ring by an in-place producer (acquire /
+// push), two buffers in flight, every list popped; runs for about `seconds`.  bench.py reports it next to `value`
+// (which is the HBM-resident rate and never includes PCIe).
+extern "C" int adsb_measure_feed(int device, int sample_type, size_t chunk, double seconds, double *us_per_buffer,
+                                 double *frames_per_buffer, uint64_t *buffers)
+{
+    if (!us_per_buffer || chunk < (size_t)kWindow || seconds <= 0 || (sample_type != ADSB_SAMPLE_I8 && sample_type != ADSB_SAMPLE_I16))
+        return ADSB_E_ARG;
+    const size_t bps = sample_type == ADSB_SAMPLE_I8 ? 2 : 4;
+    adsb_synth_cfg sc;
+    adsb_synth_default(&sc);
+    sc.seed = 9;
+    if (sample_type == ADSB_SAMPLE_I16) sc.amp_shift = 5;
+    const int n_src = chunk <= (1u << 20) ? 8 : 2;
+    std::vector<char> data(chunk * bps * n_src);
+    int rc = adsb_synth_fill_host(&sc, sample_type, 0, 0, chunk * n_src, data.data());
+    if (rc != ADSB_OK) return rc;
+    adsb_cfg cfg{};
+    cfg.abi_version = ADSB_ABI_VERSION;
+    cfg.device = device;
+    cfg.sample_type = sample_type;
+    cfg.max_channels = 1;
+    cfg.max_samples = chunk + kWindow;
+    cfg.max_out = chunk / 200 + 4096;
+    adsb_ctx *ctx = nullptr;
+    if ((rc = adsb_create(&cfg, &ctx)) != ADSB_OK) return rc;
+    adsb_feed_cfg fc{};
+    fc.max_chunk = chunk;
+    fc.carry = 0;
+    fc.ring_slots = 3;
+    adsb_feed *feed = nullptr;
+    if ((rc = adsb_feed_open(ctx, &fc, &feed)) != ADSB_OK) { adsb_destroy(ctx); return rc; }
+    std::vector<adsb_frame> frames(cfg.max_out);
+    uint64_t total = 0, n_buf = 0;
+    auto one = [&](uint64_t k, bool fill) {
+        void *slot = nullptr;
+        int r = adsb_feed_acquire(feed, &slot);
+        // (a real producer -- SDR driver, file reader -- writes its samples straight into the slot: that is its cost, not
+        // the hand-over's; the slots are filled during the warm-up rounds)
+        if (r == ADSB_OK && fill) std::memcpy(slot, data.data() + (size_t)(k % n_src) * chunk * bps, chunk * bps);
+        if (r == ADSB_OK) r = adsb_feed_push(feed, nullptr, chunk);
+        if (r == ADSB_OK && adsb_feed_in_flight(feed) == 2) {
+            size_t n = 0;
+            r = adsb_feed_pop(feed, frames.data(), frames.size(), &n, nullptr, nullptr);
+            total += n;
+        }
+        return r;
+    };
+    auto drain = [&]() {
+        int r = ADSB_OK;
+        while (r == ADSB_OK && adsb_feed_in_flight(feed) > 0) {
+            size_t n = 0;
+            r = adsb_feed_pop(feed, frames.data(), frames.size(), &n, nullptr, nullptr);
+            total += n;
+        }
+        return r;
+    };
+    for (uint64_t k = 0; k < 6 && rc == ADSB_OK; ++k) rc = one(k, true);
+    if (rc == ADSB_OK) rc = drain();
+    total = 0;
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    double dt = 0;
+    while (rc == ADSB_OK) {
+        for (int k = 0; k < 16 && rc == ADSB_OK; ++k, ++n_buf) rc = one(n_buf + 6, false);
+        dt = std::chrono::duration<double>(clk::now() - t0).count();
+        if (dt >= seconds) break;
+    }
+    if (rc == ADSB_OK) rc = drain();
+    dt = std::chrono::duration<double>(clk::now() - t0).count();
+    adsb_feed_close(feed);
+    adsb_destroy(ctx);
+    if (rc != ADSB_OK) return rc;
+    *us_per_buffer = n_buf ? dt * 1e6 / (double)n_buf : 0.0;
+    if (frames_per_buffer) *frames_per_buffer = n_buf ? (double)total / (double)n_buf : 0.0;
+    if (buffers) *buffers = n_buf;
+    return ADSB_OK;
+}
+
+// The box's pinned host -> device copy rate (one stream, `bytes` per copy): the ceiling of any host-fed path.
+extern "C" int adsb_measure_pinned_copy(int device, size_t bytes, int iters, double *gbytes_per_s)
+{
+    if (!gbytes_per_s || bytes == 0 || iters <= 0) return ADSB_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    void *h = nullptr, *d = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&d, bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0;
+    if (e == hipSuccess) {
+        std::memset(h, 1, bytes);
+        e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s); // warm-up
+        if (e == hipSuccess) e = hipEventRecord(e0, s);
+        for (int k = 0; k < iters && e == hipSuccess; ++k) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+    (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    if (e != hipSuccess) return (int)e;
+    *gbytes_per_s = ms > 0 ? (double)bytes * iters / (ms * 1e-3) / 1e9 : 0.0;
     return ADSB_OK;
 }
 

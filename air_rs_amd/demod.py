@@ -43,6 +43,21 @@ def synth_fill_host(cfg, sample_type, channel, first_sample, n_samples):
     return out
 
 
+def measure_feed(device, sample_type, chunk, seconds=0.15):
+    """(us per buffer, frames per buffer, buffers) of the streaming front end fed from pinned HOST memory, timed in C."""
+    us, fr, nb = C.c_double(), C.c_double(), C.c_uint64()
+    L.check(L.load().adsb_measure_feed(int(device), int(sample_type), int(chunk), float(seconds), C.byref(us), C.byref(fr),
+                                       C.byref(nb)), "adsb_measure_feed")
+    return us.value, fr.value, nb.value
+
+
+def measure_pinned_copy(device, nbytes=64 << 20, iters=8):
+    """Pinned host -> device copy rate of this box in GB/s."""
+    g = C.c_double()
+    L.check(L.load().adsb_measure_pinned_copy(int(device), int(nbytes), int(iters), C.byref(g)), "adsb_measure_pinned_copy")
+    return g.value
+
+
 def synth_slot(cfg, channel, slot):
     start = C.c_uint64()
     clean = (C.c_uint8 * 14)()

@@ -416,6 +416,24 @@ def main():
         if rehearsal:
             out["rehearsal"] = f"{world} ranks sharing one GPU, frame lists over gloo through pinned host memory: a functional run of the N-GPU path, its throughput is not a measurement"
 
+        if world == 1 and not args.no_feed:
+            # The PCIe-inclusive rates (never `value`): buffers that arrive in HOST memory, through the streaming front end
+            # (adsb_feed_*: pinned ring, two in flight), timed in C after the timed region -- the reference's own playback
+            # buffer (20 000 samples, src/adsb.rs:77-79) and 16 Mi-sample buffers, against the box's pinned-copy rate.
+            try:
+                us_small, fr_small, nb_small = A.measure_feed(local_rank, st, 20000, 0.15)
+                big = 1 << 24
+                us_big, fr_big, nb_big = A.measure_feed(local_rank, st, big, 0.25)
+                pin = A.measure_pinned_copy(local_rank, 64 << 20, 8)
+                out["feed"] = {"what": "host-fed (PCIe-inclusive) rate of adsb_feed_*: in-place producer, two buffers in flight, every frame list popped; measured after the timed region, not part of value",
+                               "us_per_20000_sample_buffer": round(us_small, 2), "msamples_per_s_20000": round(20000 / us_small, 1),
+                               "frames_per_20000_sample_buffer": round(fr_small, 2), "buffers_20000": int(nb_small),
+                               "gsamples_per_s": round(big / us_big / 1e3, 3), "gbytes_per_s": round(big * bps / us_big / 1e3, 2),
+                               "large_buffer_samples": big, "buffers_large": int(nb_big),
+                               "pinned_copy_ceiling_gbps": round(pin, 2), "frac_of_pinned_copy": round(big * bps / us_big / 1e3 / pin, 3) if pin > 0 else None}
+            except Exception as e:  # noqa: BLE001  (the courtesy figures must never cost the bench line)
+                out["feed"] = {"error": f"{type(e).__name__}: {e}"}
+
         if world == 1 and not args.no_cpu_baseline and bps == 2 and nch == 1:
             sample = iq.cpu().numpy().reshape(-1, 2)  # the whole buffer: ~6-10 s on one host core
             gpu_frames = dem.fetch()[0]               # the last timed launch's list (same buffer every step)

@@ -337,6 +337,14 @@ int adsb_timing_read(adsb_ctx *ctx, double *demod_ms_mean, double *order_ms_mean
  * loads and returns the mean milliseconds per pass. */
 int adsb_time_read_ceiling(adsb_ctx *ctx, const void *buf_dev, size_t bytes, int iters,
                            double *ms_per_pass);
+/* Measurement: what one buffer costs when it comes from HOST memory through the streaming front end (adsb_feed_*, defined
+ * further down; reference: src/adsb.rs:75-89 sends 20 000-sample buffers, adsb.rs:59-64 MTU-sized ones), timed from C with a
+ * context and a feed of its own on `device`: in-place producer, two buffers in flight, every list popped, for about
+ * `seconds`.  PCIe-inclusive by construction; bench.py prints it next to (never as) the HBM-resident `value`. */
+int adsb_measure_feed(int device, int sample_type, size_t chunk_samples, double seconds, double *us_per_buffer,
+                      double *frames_per_buffer, uint64_t *buffers);
+/* Measurement: pinned host -> device copy rate of this box (GB/s), the ceiling of any host-fed path. */
+int adsb_measure_pinned_copy(int device, size_t bytes, int iters, double *gbytes_per_s);
 /* floor(sqrt(I^2+Q^2)) of n host samples through the device magnitude code (utils.rs:46-52). */
 int adsb_debug_magnitudes(adsb_ctx *ctx, const void *iq_host, size_t n_samples,
                           uint16_t *mags_host);

@@ -169,7 +169,7 @@ def test_code_table_is_a_superset_table(gpu, monkeypatch):
     assert (th[64:] - code[64:]).max() <= 6 and np.median(th[256:] - code[256:]) <= 3
 
 
-@pytest.mark.parametrize("div,slot", [(72, 2000), (36, 900), (18, 400), (9, 300), (4, 250)])
+@pytest.mark.parametrize("div,slot", [(72, 2000), (36, 900), (18, 400), (9, 300), (4, 260)])
 def test_code_scan_at_every_level(gpu, oracle, monkeypatch, div, slot):
     """Noise from sigma ~ 2 (codes tie almost everywhere: most survivors of the code gate are decided from the samples
     themselves) to sigma ~ 36 (clipping), dense frames: the code scan's list equals the oracle's."""
