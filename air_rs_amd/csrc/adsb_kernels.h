@@ -148,6 +148,7 @@ constexpr int kFinishTilesPerWg = 32;
 hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, const DemodArgs &p, const FinishArgs &f,
                         const SmallArgs &sm);
 
+bool ab_kernels_built();  // -DADSB_AB_KERNELS=1: the A/B scan kernels (nsq, reg, code) are in this library
 bool tile_stamps_built(); // -DADSB_TILE_STAMPS=1 diagnostic build: DemodArgs::stamps holds 64 bytes per tile
 
 // field decode of an ordered frame list (count read from hdr->n_out on the device)

@@ -565,6 +565,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const DemodArgs &p, 
 #ifndef ADSB_ABL_NOCMP
 #define ADSB_ABL_NOCMP 0 // measurement only (wrong results): gate without compares and branches
 #endif
+// The product library carries ONE i8 scan kernel (kScanRoot; x its three magnitude modes) and CS16's.  The kernels round 3 and
+// round 4 measured against it -- kScanNsq, kScanReg, kScanCode: all bit-exact, none faster -- are compiled only with
+// -DADSB_AB_KERNELS=1 (build.sh puts that build in air_rs_amd/lib/variants/libadsb_hip_ab.so; tests/test_gpu_ab_kernels.py
+// runs one parity smoke per kernel through it; tools/gpu/ab.sh times them).
+#ifndef ADSB_AB_KERNELS
+#define ADSB_AB_KERNELS 0
+#endif
+bool ab_kernels_built() { return ADSB_AB_KERNELS != 0; }
+#ifndef ADSB_PRIO
+#define ADSB_PRIO 0 // A/B (s_setprio): 1 = prologue + loads at priority 3, 2 = phase 3 at priority 2, 3 = both
+#endif
 #ifndef ADSB_GATE_GROUP
 #define ADSB_GATE_GROUP 1 // steps per wave-uniform test in demod_tiles (see gate_phase)
 #endif
@@ -1066,6 +1077,9 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
 
+#if ADSB_PRIO & 1 // (A/B: a new workgroup's prologue and loads go out ahead of the resident waves' arithmetic)
+    __builtin_amdgcn_s_setprio(3);
+#endif
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 3);
 #if ADSB_TILE_STAMPS
     unsigned long long ts_prev = 0;
@@ -1084,6 +1098,9 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
         u32x4 raw_a[NSQ ? kNsqIters : 1], raw_b[NSQ ? kNsqIters : 1];
         if constexpr (NSQ) nsq_issue_loads(p, tp, tid, raw_a, raw_b);
         else issue_tile_loads<ST>(p, tp, true, tid, raw);
+#if ADSB_PRIO & 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         TSTAMP(0); // prologue, loads issued
         if (tid == 0 && first) {
             p.hdr->retry = 0;
@@ -1137,6 +1154,9 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
         __syncthreads();
         TSTAMP(4); // barrier
 
+#if ADSB_PRIO & 2 // (A/B: the tail of a tile ahead of other waves' arithmetic: the workgroup retires, the next one's loads start)
+        __builtin_amdgcn_s_setprio(2);
+#endif
         // [phase:3 hand-over: slots, offsets, sliced bytes]
         // ---- phase 3: PPM slice of the gate survivors; the CRC stage is a kernel of its own --------------------
         // Every survivor gets a frame slot, its absolute offset and its 14 sliced bytes (the image is here, in
@@ -2016,11 +2036,13 @@ __device__ __forceinline__ void scan_tile_reg(const DemodArgs &p, const uint32_t
     }
 }
 
+#if ADSB_AB_KERNELS
 __global__ __launch_bounds__(kThreads, ADSB_REG_WAVES) void demod_tiles_reg(DemodArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RegLds::kTotal];
     scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
 }
+#endif
 
 // ---- the code scan (i8, kScanCode): the gate on an 8-bit LOG code of n = I^2 + Q^2, no root per sample --------------------
 // The root scan spends 3.5 of its 5.5 phase-1 issue slots per sample on floor(sqrt(n)) (v_sqrt_f32 alone holds the SIMD
@@ -2525,11 +2547,13 @@ __device__ __forceinline__ void scan_tile_code(const DemodArgs &p, const uint32_
     }
 }
 
+#if ADSB_AB_KERNELS
 __global__ __launch_bounds__(kThreads, 8) void demod_tiles_code(DemodArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CodeLds::kTotal];
     scan_tile_code(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
 }
+#endif
 
 // ---- small buffers: scan + finish in ONE dispatch, results straight into host memory --------------------------------------
 // A buffer of at most kFinTiles tiles (the reference's own buffers: 20 000 samples = 2 tiles, adsb.rs:77-79; an SDR's MTU-
@@ -2584,9 +2608,13 @@ hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, 
     if (p.tile_count == 0 || p.tile_count > (uint32_t)kFinTiles) return hipErrorInvalidValue;
     dim3 grid(p.tile_count), block(kThreads);
     if (sample_type == ADSB_SAMPLE_I16) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I16, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
+#if ADSB_AB_KERNELS
     else if (scan == kScanNsq) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanNsq>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanReg) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanReg>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanCode) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanCode>), grid, block, 0, s, p, f, sm);
+#else
+    else if (scan != kScanRoot) return hipErrorInvalidValue; // (the A/B kernels are not in this build)
+#endif
     else if (mag_mode == 0) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
     else if (mag_mode == 1) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 1, kScanRoot>), grid, block, 0, s, p, f, sm);
     else hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 2, kScanRoot>), grid, block, 0, s, p, f, sm);
@@ -2635,6 +2663,7 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (a.tile_count == 0) return hipSuccess;
+#if ADSB_AB_KERNELS
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
         hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq>), dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
@@ -2647,6 +2676,9 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
         hipExtLaunchKernelGGL(demod_tiles_code, dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
+#else
+    if (sample_type == ADSB_SAMPLE_I8 && scan != kScanRoot) return hipErrorInvalidValue; // (the A/B kernels are not in this build)
+#endif
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);
     return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count, e0, e1);
 }

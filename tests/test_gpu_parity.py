@@ -10,11 +10,12 @@ import air_rs_amd as A
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["code", "root", "nsq", "reg"], autouse=True)
+@pytest.fixture(scope="module", params=["root"], autouse=True)
 def scan_kind(request):
-    """Every i8 test of this module runs once per i8 scan kernel: "root" (floor(sqrt) per sample, u8 magnitudes in LDS),
-    "nsq" (the gate on I^2+Q^2 over an LDS image) and "reg" (the same gate from registers: chunks of 4032 offsets per wave,
-    tiles of 16128) -- all selectable, so all must stay bit-exact.  ADSB_SCAN is read by adsb_create."""
+    """Every i8 test of this module runs once per i8 scan kernel the PRODUCT library carries: "root" (floor(sqrt) per sample,
+    u8 magnitudes in LDS).  The kernels measured against it ("code", "nsq", "reg": bit-exact, none faster) live in the
+    -DADSB_AB_KERNELS=1 build only; tests/test_gpu_ab_kernels.py runs this module's core cases through that library, once per
+    kernel.  ADSB_SCAN is read by adsb_create."""
     old = os.environ.get("ADSB_SCAN")
     os.environ["ADSB_SCAN"] = request.param
     yield request.param

@@ -134,7 +134,7 @@ def test_small_buffer_path_equals_three_kernel_path(gpu, oracle, monkeypatch):
     # (tile = 16384 offsets for i8, 8192 for CS16: the 32-tile edge of the one-dispatch path lies at both)
     sizes = [241, 1000, 8192 + 240, 16128 + 240, 16128 + 241, 16384 + 240, 16384 + 241, 20000, 3 * 16384 + 777, 32 * 8192 + 240,
              32 * 8192 + 241, 32 * 16128 + 240, 32 * 16128 + 241, 32 * 16384 + 240, 32 * 16384 + 241, 600_000]
-    for st, scan in ((A.ADSB_SAMPLE_I8, "root"), (A.ADSB_SAMPLE_I8, "nsq"), (A.ADSB_SAMPLE_I8, "reg"), (A.ADSB_SAMPLE_I16, "root")):
+    for st, scan in ((A.ADSB_SAMPLE_I8, "root"), (A.ADSB_SAMPLE_I16, "root")):
         monkeypatch.setenv("ADSB_SCAN", scan)
         cfg = A.synth_default(seed=61, slot_len=500)
         if st == A.ADSB_SAMPLE_I16:
@@ -156,22 +156,20 @@ def test_small_buffer_path_equals_three_kernel_path(gpu, oracle, monkeypatch):
 
 
 def test_scan_kernel_selection(gpu, monkeypatch):
-    """ADSB_SCAN at adsb_create: default and "root" = the product's i8 scan kernel, "nsq" = the A/B kernel, anything
-    else is refused; CS16 has one kernel."""
+    """ADSB_SCAN at adsb_create: default and "root" = the product's i8 scan kernel; the A/B kernels ("code", "nsq", "reg") are
+    not in the product library and asking for one is an error, like any unknown name; CS16 has one kernel."""
     monkeypatch.delenv("ADSB_SCAN", raising=False)
     with A.AdsbDemod(max_samples=4096, max_out=16) as d:
         assert d.scan == "root"
-    monkeypatch.setenv("ADSB_SCAN", "nsq")
+    monkeypatch.setenv("ADSB_SCAN", "root")
     with A.AdsbDemod(max_samples=4096, max_out=16) as d:
-        assert d.scan == "nsq"
-    monkeypatch.setenv("ADSB_SCAN", "reg")
-    with A.AdsbDemod(max_samples=4096, max_out=16) as d:
-        assert d.scan == "reg"
-    monkeypatch.setenv("ADSB_SCAN", "stream")
-    with pytest.raises(A.AdsbError) as e:
-        A.AdsbDemod(max_samples=4096, max_out=16)
-    assert e.value.code == A.ADSB_E_ARG
-    monkeypatch.setenv("ADSB_SCAN", "nsq")
+        assert d.scan == "root"
+    for name in ("code", "nsq", "reg", "stream"):
+        monkeypatch.setenv("ADSB_SCAN", name)
+        with pytest.raises(A.AdsbError) as e:
+            A.AdsbDemod(max_samples=4096, max_out=16)
+        assert e.value.code == A.ADSB_E_ARG
+    monkeypatch.setenv("ADSB_SCAN", "root")
     with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I16, max_samples=4096, max_out=16) as d:
         assert d.scan == "root"
 
