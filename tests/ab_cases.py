@@ -80,12 +80,18 @@ def test_small_path_and_two_kernel_path(gpu, oracle, monkeypatch):
 
 def test_slot_pool_loss_is_repaired(gpu, oracle):
     """tiles over their 32 slots lose them (adsb_debug_pool_limit): counted in place, re-run by the host"""
-    rng = np.random.default_rng(9)
-    iq = rng.integers(-2, 3, size=(300_000, 2), dtype=np.int8)
+    cfg = A.synth_default(seed=19, slot_len=600)
+    iq = A.synth_fill_host(cfg, A.ADSB_SAMPLE_I8, 0, 0, 300_000).copy()
+    iq[40_000:95_000] = (3, 4)            # constant: one frame per offset (SURVEY F8), three whole tiles and two part ones
+    iq[200_000:200_300] = 0
     rc, want, n = oracle.process_buffer(iq, max_out=1 << 18)
-    assert rc == 0 and n > 5000
+    assert rc == 0 and n > 50_000
     with A.AdsbDemod(max_samples=300_000, max_out=1 << 18) as d:
         d.pool_limit(True)
+        frames, flags = d.demod(iq)
+        d.pool_limit(False)
+        assert flags == 0
+        _eq(frames, want)
         frames, flags = d.demod(iq)
         assert flags == 0
         _eq(frames, want)
