@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def derived(d, samples, bps):
@@ -24,6 +24,11 @@ def derived(d, samples, bps):
         "lds_bank_conflict_share_of_lds_active": round(d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1), 3),
         "hbm_bytes_per_launch_fetch_size_x2": int(d["FETCH_SIZE"] * 1024 * 2),
         "algorithmic_bytes_per_launch": samples * bps,
+        # the clock the chip held in the counter pass: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS)
+        "kernel_ms_in_counter_pass": (round(d["KERNEL_NS_IN_GRBM_PASS"] * 1e-6, 4) if d.get("KERNEL_NS_IN_GRBM_PASS") else None),
+        "effective_clock_ghz": (round(d["GRBM_GUI_ACTIVE"] / 8.0 / d["KERNEL_NS_IN_GRBM_PASS"], 3) if d.get("KERNEL_NS_IN_GRBM_PASS") else None),
+        # share of the SIMDs' VALU issue capacity (one wave64 instruction per 4 cycles per SIMD, 1024 SIMDs) the kernel used
+        "valu_issue_utilisation": (round(d["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3) if d.get("GRBM_GUI_ACTIVE") else None),
     }
 
 
@@ -33,6 +38,8 @@ nsq_path = os.path.join(G, "r_pmc_summary_nsq.json")
 nsq = json.load(open(nsq_path)) if os.path.exists(nsq_path) else None
 reg_path = os.path.join(G, "r_pmc_summary_reg.json")
 reg = json.load(open(reg_path)) if os.path.exists(reg_path) else None
+code_path = os.path.join(G, "r_pmc_summary_code.json")
+code = json.load(open(code_path)) if os.path.exists(code_path) else None
 old = json.load(open(os.path.join(P, "pmc_summary.json")))
 before = old.get("before_the_split") or {"note": "demod_tiles with the whole decode inside (round 1 .. mid round 2)",
                                          "i8": old.get("i8", {}).get("demod_tiles", {}).get("derived"),
@@ -40,7 +47,7 @@ before = old.get("before_the_split") or {"note": "demod_tiles with the whole dec
                                          "cs16": old.get("cs16", {}).get("demod_tiles", {}).get("derived"),
                                          "round_1": old.get("round_1")}
 new = {
-    "round": "round 3",
+    "round": "round 4",
     "note": "rocprofv3 --pmc passes over `bench.py --steps 4 --warmup 1` (tools/gpu/pmc_passes.sh; `--sample-type i16` for CS16), "
             "mean per launch of the named kernel on the 1 GiB workload; FETCH_SIZE is in KiB and is doubled per MI355X_MICROARCH.md "
             "(gfx950 reports half of a wide streaming read); SQ_* cycle counters are in quad-cycles summed over waves, GRBM_GUI_ACTIVE "
@@ -59,6 +66,8 @@ new = {
     "i8_nsq_scan": ({"demod_tiles": {"derived": derived(nsq["demod_tiles"], 1 << 29, 2), "raw": nsq["demod_tiles"]}} if nsq else None),
     # the register scan (ADSB_SCAN=reg: the same gate from registers, no LDS image)
     "i8_reg_scan": ({"demod_tiles": {"derived": derived(reg["demod_tiles"], 1 << 29, 2), "raw": reg["demod_tiles"]}} if reg else None),
+    # the code scan (round 4, ADSB_SCAN=code in the -DADSB_AB_KERNELS=1 build: the gate on an 8-bit log code of I^2+Q^2, no root per sample)
+    "i8_code_scan": ({"demod_tiles": {"derived": derived(code["demod_tiles"], 1 << 29, 2), "raw": code["demod_tiles"]}} if code else None),
     "before_the_split": before,
     # the scan kernel's PMC rows as it was trimmed after the split (each measured by the same passes, one MI355X box each)
     "demod_tiles_i8_history": [
@@ -79,7 +88,7 @@ new = {
     ],
 }
 json.dump(new, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
-for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"), ("r_bench_reg.json", "bench_reg_scan.json"),
+for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"), ("r_bench_reg.json", "bench_reg_scan.json"), ("r_bench_code.json", "bench_code_scan.json"),
                  ("r_feed_bench.txt", "feed_bench.txt"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
                  ("r_bench_cs16_16g.json", "bench_cs16_16GiB.json"), ("r_bench_64ch.json", "bench_64_channels.json"),
                  ("r_kernel_stats.csv", "kernel_stats.csv"), ("r_kernel_stats_16g.csv", "kernel_stats_16GiB.csv")):
