@@ -10,22 +10,29 @@
 //   88 data bits, which is then flipped)                            (src/adsb/crc.rs:49-65)
 // Every offset is independent (the `_i += 240` at adsb.rs:113 has no effect).
 //
-// Mapping to the machine (no MFMA: this is an HBM-bound stencil + sparse decode):
-//   * one workgroup = one tile of kTile offsets; the tile's raw IQ is read once, coalesced,
-//     16 B per lane through a bounds-checked buffer descriptor (tails read as zero);
-//   * magnitudes are produced in registers (v_dot4_i32_i8 -> v_sqrt_f32 -> v_cvt_pk_u8_f32)
-//     and parked in LDS as u8 (i8 input) or u16 (i16 input);
-//   * the gate runs "transposed": each lane slides along its own run of kRun consecutive
-//     offsets, two runs packed in the halves of one VGPR so every min/max is one
-//     packed instruction for two offsets (3-input v_pk_maximum3_f16 / v_pk_minimum3_f16 where the
-//     values allow it); running maxima/minima are shared between neighbouring offsets, so the
-//     preamble test costs 4.5 VALU instructions per offset;
-//   * survivors are kept as a per-lane 64-bit mask -> LDS bitmap -> ordered list (wave prefix
-//     sums), then decoded by 16-lane groups (one lane per frame byte) straight from the LDS
-//     magnitudes, with a 112-entry syndrome table for CRC and single-bit repair;
-//   * frames go to per-tile slots; a gather pass (tile positions from two levels of group
-//     counters, no separate scan) puts them in ascending (channel, offset) order -- the order
-//     the reference's mpsc channel would deliver them in.
+// Mapping to the machine (no MFMA: an elementwise / stencil path; HBM-bound by design, VALU-issue-bound as measured --
+// DESIGN.md section 5).  A launch is two kernels:
+//   demod_tiles (the SCAN: every IQ byte is read once)
+//   * one workgroup = one tile of kTile offsets; the tile's raw IQ is read coalesced, 16 B per lane, all loads in flight
+//     before the first use, through a bounds-checked buffer descriptor (tails read as zero);
+//   * phase 1: magnitudes in registers (v_dot4_i32_i8 -> v_sqrt_f32 -> v_cvt_pk_u8_f32), parked in LDS as u8 (i8 input)
+//     or u16 (CS16);
+//   * phase 2: the gate runs "transposed": each lane slides along its own run of kRun consecutive offsets, two runs
+//     packed in the halves of one VGPR so every min/max is one packed instruction for two offsets (3-input
+//     v_pk_maximum3_f16 / v_pk_minimum3_f16 on the magnitudes as f16 bit patterns); running maxima / minima are shared
+//     between neighbouring offsets: 8 VALU per step of two offsets; the DF17 part only where some lane of the wave passes
+//     the preamble part;
+//   * phase 3: the few survivors (LDS bitmap -> unordered list; prefix sums when dense) are sliced by 16-lane groups, one
+//     lane per frame byte, straight from the LDS magnitudes; offset + 14 bytes go to the survivor's slot (every tile owns
+//     kQuota slots; more come from a shared pool).  No CRC here.
+//   finish_order (latency-bound, ~10 us): one LANE per survivor -- CRC-24 by byte table, single-bit repair by binary
+//   search of the 88 sorted syndromes, rank inside the tile by DPP rotations, the tile's place from an exchange of
+//   per-workgroup counts inside the kernel -- writes the frames in ascending (channel, offset) order, the order the
+//   reference's mpsc channel would deliver them in.
+// Buffers of at most 32 tiles (the reference's own 20 000-sample buffers) take ONE dispatch (demod_small: the tile body
+// per workgroup, the last workgroup to arrive runs the finishing block and writes into pinned host memory).
+// The product library carries one i8 scan (kScanRoot) and CS16's; the kernels measured against it (kScanNsq, kScanReg,
+// kScanCode: bit-exact, none faster) are compiled with -DADSB_AB_KERNELS=1 only.
 #include <hip/hip_ext.h>
 
 #include "adsb_kernels.h"
@@ -99,8 +106,9 @@ __device__ __forceinline__ void dot4x8_sacc(u32x4 v, int c, int n[8])
           "v"(a6), "v"(a7), "s"(c));
 }
 
-// CRC-24 syndrome table: kSyn[j] = x^(111-j) mod 0x1FFF409, j = 0..111 (bit j MSB-first of the
-// 112-bit frame).  XOR over the set bits of a frame is CRC24(data) ^ crc_field; for j < 88 it is
+// CRC-24 syndrome table (used by count_candidate only -- tiles that lost their slots are counted in place, a cold
+// path; finish_order has its own byte table and sorted syndromes): kSyn[j] = x^(111-j) mod 0x1FFF409, j = 0..111 (bit j
+// MSB-first of the 112-bit frame).  XOR over the set bits of a frame is CRC24(data) ^ crc_field; for j < 88 it is
 // also the syndrome of a single error in data bit j (the 88 values are distinct and non-zero,
 // which is why the reference's ordered brute force, crc.rs:49-65, has at most one match).
 struct SynTable {
