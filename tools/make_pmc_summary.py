@@ -91,7 +91,7 @@ json.dump(new, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"), ("r_bench_reg.json", "bench_reg_scan.json"), ("r_bench_code.json", "bench_code_scan.json"),
                  ("r_feed_bench.txt", "feed_bench.txt"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
                  ("r_bench_cs16_16g.json", "bench_cs16_16GiB.json"), ("r_bench_64ch.json", "bench_64_channels.json"),
-                 ("r_kernel_stats.csv", "kernel_stats.csv"), ("r_kernel_stats_16g.csv", "kernel_stats_16GiB.csv")):
+                 ("r_kernel_stats.csv", "kernel_stats.csv"), ("prof_bench.json", "bench_under_rocprofv3.json"), ("r_kernel_stats_16g.csv", "kernel_stats_16GiB.csv")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, f"{tag}_{dst}"))
 for k in ("i8", "cs16"):
