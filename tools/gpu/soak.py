@@ -12,6 +12,7 @@ from tests.oracle_binding import Oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--scans", default="root", help="i8 scan kernels to soak (the A/B build also has code,nsq,reg)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 orc = Oracle()
@@ -20,21 +21,18 @@ def make(st, max_samples, max_out, scan="root", small_path="1"):
     return A.AdsbDemod(sample_type=st, max_samples=max_samples, max_out=max_out)
 
 
-# every kernel variant: i8 root scan (the product's), i8 nsq scan (the A/B kernel), CS16; the one-dispatch path for small
-# buffers on (default) and off; and small frame capacities (dense inputs overflow the slot pool and are re-planned)
-ctx = {(A.ADSB_SAMPLE_I8, "root"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19),
-       (A.ADSB_SAMPLE_I8, "nsq"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="nsq"),
-       (A.ADSB_SAMPLE_I8, "reg"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="reg"),
-       (A.ADSB_SAMPLE_I8, "reg-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="reg", small_path="0"),
-       (A.ADSB_SAMPLE_I8, "root-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, small_path="0"),
-       (A.ADSB_SAMPLE_I8, "nsq-3k"): make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan="nsq", small_path="0"),
-       (A.ADSB_SAMPLE_I16, "root"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19),
+# every kernel the loaded library carries: i8 root scan (the product's; with ADSB_HIP_LIB pointing at the -DADSB_AB_KERNELS=1
+# build and --scans root,code,nsq,reg also the A/B kernels), CS16; the one-dispatch path for small buffers on (default) and
+# off; and small frame capacities (dense inputs overflow the slot pool and are re-planned)
+SCANS = args.scans.split(",")
+ctx = {(A.ADSB_SAMPLE_I16, "root"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19),
        (A.ADSB_SAMPLE_I16, "root-3k"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19, small_path="0"),
-       (A.ADSB_SAMPLE_I8, "small"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000),
-       (A.ADSB_SAMPLE_I8, "small-nsq"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, scan="nsq"),
-       (A.ADSB_SAMPLE_I8, "small-reg"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, scan="reg"),
-       (A.ADSB_SAMPLE_I8, "small-3k"): make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, small_path="0"),
        (A.ADSB_SAMPLE_I16, "small"): make(A.ADSB_SAMPLE_I16, 1 << 20, 3000)}
+for sc in SCANS:
+    ctx[(A.ADSB_SAMPLE_I8, sc)] = make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan=sc)
+    ctx[(A.ADSB_SAMPLE_I8, sc + "-3k")] = make(A.ADSB_SAMPLE_I8, 1 << 22, 1 << 19, scan=sc, small_path="0")
+    ctx[(A.ADSB_SAMPLE_I8, "small-" + sc)] = make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, scan=sc)
+ctx[(A.ADSB_SAMPLE_I8, "small-root-3k")] = make(A.ADSB_SAMPLE_I8, 1 << 20, 3000, small_path="0")
 t0 = time.time()
 runs = fails = frames_total = 0
 t_note = t0
@@ -43,11 +41,11 @@ while time.time() - t0 < args.seconds:
         t_note = time.time()
         print(f"  ... {runs} buffers, {fails} mismatches after {t_note - t0:.0f} s", flush=True)
     st = A.ADSB_SAMPLE_I8 if rng.random() < 0.7 else A.ADSB_SAMPLE_I16
-    kern = str(rng.choice(["root", "nsq", "reg", "root-3k", "nsq-3k", "reg-3k"])) if st == A.ADSB_SAMPLE_I8 else str(rng.choice(["root", "root-3k"]))
+    kern = str(rng.choice([k for sc in SCANS for k in (sc, sc + "-3k")])) if st == A.ADSB_SAMPLE_I8 else str(rng.choice(["root", "root-3k"]))
     n = int(rng.choice([rng.integers(240, 4000), rng.integers(4000, 200000), rng.integers(200000, 3000000)]))
     dense = rng.random() < 0.06
     if dense:
-        kern = str(rng.choice(["small", "small-nsq", "small-reg", "small-3k"])) if st == A.ADSB_SAMPLE_I8 else "small"
+        kern = str(rng.choice(["small-" + sc for sc in SCANS] + ["small-root-3k"])) if st == A.ADSB_SAMPLE_I8 else "small"
         n = min(n, 1 << 20)
     cfg = A.synth_default(seed=int(rng.integers(1, 1 << 40)), slot_len=int(rng.choice([300, 600, 2000, 9000])))
     cfg.noise_div = int(rng.choice([3, 8, 18, 60, 200]))
