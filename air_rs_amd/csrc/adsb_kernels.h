@@ -42,17 +42,19 @@ constexpr int kTileMax = kTile > 2 * kThreads * kRunI16 ? kTile : 2 * kThreads *
 //   kScanRoot: floor(sqrt(n)) per sample (v_sqrt_f32), u8 magnitudes in LDS -- the product's kernel
 //   kScanNsq : the gate runs on n = I^2+Q^2 (no root per sample; exact: DESIGN.md section 4.1b), 2 bytes of LDS per
 //              sample; the round-3 A/B kernel (fewer VALU slots, half the resident workgroups: slower)
-constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2, kScanCode = 3;
+constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2, kScanCode = 3, kScanSieve = 4;
 //   kScanCode: the gate slides over an 8-bit LOG code of n = I^2+Q^2 (one quarter-rate v_cvt_pk_fp8_f32 per pair of samples
 //              instead of a root per sample); a superset test on codes, the few uncertain survivors are decided from the
 //              samples themselves (adsb_kernels.hip, "the code scan"): the product's kernel since round 4
 //   kScanReg : the nsq gate from registers, no LDS image (every wave a chunk of 4032 offsets; window overlap by DPP from
 //              the neighbouring lane); tiles of 16128 offsets
 constexpr int kRegTile = 4 * 2 * 63 * 32; // offsets per tile of the register scan: four waves x 4032
+constexpr int kSieveTile = 8192;          // offsets per tile of the sieve scan: 128 lanes x 64 (adsb_sieve.inc)
 // offsets per tile of a context (the scan kind is fixed at adsb_create)
 constexpr int tile_offsets_of(int sample_type, int scan)
 {
-    return (sample_type == ADSB_SAMPLE_I8 && scan == kScanReg) ? kRegTile : tile_offsets(sample_type);
+    return (sample_type == ADSB_SAMPLE_I8 && scan == kScanReg) ? kRegTile
+           : (sample_type == ADSB_SAMPLE_I8 && scan == kScanSieve) ? kSieveTile : tile_offsets(sample_type);
 }
 constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
 constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path

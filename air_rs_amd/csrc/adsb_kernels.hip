@@ -34,6 +34,7 @@
 // The product library carries one i8 scan (kScanRoot) and CS16's; the kernels measured against it (kScanNsq, kScanReg,
 // kScanCode: bit-exact, none faster) are compiled with -DADSB_AB_KERNELS=1 only.
 #include <hip/hip_ext.h>
+#include <utility>
 
 #include "adsb_kernels.h"
 #include "adsb_synth.h"
@@ -2563,6 +2564,8 @@ __global__ __launch_bounds__(kThreads, 8) void demod_tiles_code(DemodArgs p)
 }
 #endif
 
+#include "adsb_sieve.inc"
+
 // ---- small buffers: scan + finish in ONE dispatch, results straight into host memory --------------------------------------
 // A buffer of at most kFinTiles tiles (the reference's own buffers: 20 000 samples = 2 tiles, adsb.rs:77-79; an SDR's MTU-
 // sized reads, adsb.rs:59-64) is not worth three host calls per kernel and a copy each way: one workgroup per tile runs the
@@ -2574,10 +2577,11 @@ static_assert(kFinThreads == kThreads, "the small-buffer kernel runs both bodies
 template <int ST, int MAGMODE, int SCAN>
 __global__ __launch_bounds__(kThreads, 4) void demod_small(DemodArgs p, FinishArgs f, SmallArgs sm)
 {
-    constexpr int kScanBytes = SCAN == kScanReg ? RegLds::kTotal : SCAN == kScanCode ? CodeLds::kTotal : Lds<ST, (SCAN == kScanReg || SCAN == kScanCode) ? kScanRoot : SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
+    constexpr int kScanBytes = SCAN == kScanSieve ? SieveLds::kTotal : SCAN == kScanReg ? RegLds::kTotal : SCAN == kScanCode ? CodeLds::kTotal : Lds<ST, (SCAN == kScanReg || SCAN == kScanCode || SCAN == kScanSieve) ? kScanRoot : SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kScanBytes > kFinBytes ? kScanBytes : kFinBytes];
     __shared__ uint32_t last_flag;
-    if constexpr (SCAN == kScanReg) scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    if constexpr (SCAN == kScanSieve) scan_tile_sieve<true>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    else if constexpr (SCAN == kScanReg) scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     else if constexpr (SCAN == kScanCode) scan_tile_code(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     else scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     // hand-off to whichever workgroup arrives last (cdna_hip_programming.md Guideline 16: every storing wave drains its
@@ -2616,6 +2620,7 @@ hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, 
     if (p.tile_count == 0 || p.tile_count > (uint32_t)kFinTiles) return hipErrorInvalidValue;
     dim3 grid(p.tile_count), block(kThreads);
     if (sample_type == ADSB_SAMPLE_I16) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I16, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
+    else if (scan == kScanSieve) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanSieve>), grid, block, 0, s, p, f, sm);
 #if ADSB_AB_KERNELS
     else if (scan == kScanNsq) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanNsq>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanReg) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanReg>), grid, block, 0, s, p, f, sm);
@@ -2671,6 +2676,10 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (a.tile_count == 0) return hipSuccess;
+    if (sample_type == ADSB_SAMPLE_I8 && scan == kScanSieve) {
+        hipExtLaunchKernelGGL(demod_tiles_sieve, dim3(a.tile_count), dim3(kSvThreads), 0, s, e0, e1, 0, a);
+        return hipGetLastError();
+    }
 #if ADSB_AB_KERNELS
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
         hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq>), dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
@@ -2685,7 +2694,7 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
         return hipGetLastError();
     }
 #else
-    if (sample_type == ADSB_SAMPLE_I8 && scan != kScanRoot) return hipErrorInvalidValue; // (the A/B kernels are not in this build)
+    if (sample_type == ADSB_SAMPLE_I8 && scan != kScanRoot && scan != kScanSieve) return hipErrorInvalidValue; // (the A/B kernels are not in this build)
 #endif
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);
     return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count, e0, e1);

@@ -169,7 +169,7 @@ class AdsbDemod:
         """Which scan kernel this context launches (fixed at adsb_create by ADSB_SCAN): 'code' (the default for i8: the gate
         on an 8-bit log code of I^2+Q^2), 'root' (floor(sqrt) per sample, u8 magnitudes in LDS; CS16's only one), 'nsq' /
         'reg' (the round-3 A/B kernels, in -DADSB_AB_KERNELS=1 builds only)."""
-        return {0: "nsq", 1: "root", 2: "reg", 3: "code"}[self._lib.adsb_debug_scan(self._h)]
+        return {0: "nsq", 1: "root", 2: "reg", 3: "code", 4: "sieve"}[self._lib.adsb_debug_scan(self._h)]
 
     def code_table(self):
         """The code scan's table as the device computes it: uint16[32769], c(n) | th(n) << 8."""

@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--channels", type=int, default=None,
                     help="split the per-GPU buffer into this many independent channels handled by ONE launch "
                          "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
-    ap.add_argument("--scan", choices=["default", "code", "root", "nsq", "reg"], default="default",
+    ap.add_argument("--scan", choices=["default", "code", "root", "nsq", "reg", "sieve"], default="default",
                     help="i8 scan kernel: code = the gate on an 8-bit log code of I^2+Q^2 (the product's since round 4), root = "
                          "floor(sqrt) per sample (round 1-3's), nsq / reg = the round-3 A/B kernels (-DADSB_AB_KERNELS=1 builds "
                          "only); default = the library's default (ADSB_SCAN in the environment is honoured)")

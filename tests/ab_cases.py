@@ -11,7 +11,7 @@ import air_rs_amd as A
 
 pytestmark = pytest.mark.gpu
 SCAN = os.environ.get("ADSB_SCAN", "")
-TILE = 16128 if SCAN == "reg" else 16384
+TILE = 16128 if SCAN == "reg" else 8192 if SCAN == "sieve" else 16384
 
 
 def _eq(got, want):
@@ -23,7 +23,7 @@ def _eq(got, want):
 
 @pytest.fixture(scope="module")
 def dem(gpu):
-    assert SCAN in ("code", "nsq", "reg"), "run through tests/test_gpu_ab_kernels.py"
+    assert SCAN in ("code", "nsq", "reg", "sieve"), "run through tests/test_gpu_ab_kernels.py"
     with A.AdsbDemod(sample_type=A.ADSB_SAMPLE_I8, max_samples=1 << 22, max_out=1 << 18) as d:
         assert d.scan == SCAN
         yield d
