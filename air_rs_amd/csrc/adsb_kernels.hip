@@ -35,6 +35,7 @@
 // kScanCode: bit-exact, none faster) are compiled with -DADSB_AB_KERNELS=1 only.
 #include <hip/hip_ext.h>
 #include <utility>
+#include <cstdlib>
 
 #include "adsb_kernels.h"
 #include "adsb_synth.h"
@@ -2580,7 +2581,7 @@ __global__ __launch_bounds__(kThreads, 4) void demod_small(DemodArgs p, FinishAr
     constexpr int kScanBytes = SCAN == kScanSieve ? SieveLds::kTotal : SCAN == kScanReg ? RegLds::kTotal : SCAN == kScanCode ? CodeLds::kTotal : Lds<ST, (SCAN == kScanReg || SCAN == kScanCode || SCAN == kScanSieve) ? kScanRoot : SCAN>::kTotal, kFinBytes = kFinLdsWords * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kScanBytes > kFinBytes ? kScanBytes : kFinBytes];
     __shared__ uint32_t last_flag;
-    if constexpr (SCAN == kScanSieve) scan_tile_sieve<true>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    if constexpr (SCAN == kScanSieve) scan_tile_sieve(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     else if constexpr (SCAN == kScanReg) scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     else if constexpr (SCAN == kScanCode) scan_tile_code(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
     else scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
@@ -2677,7 +2678,17 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
 {
     if (a.tile_count == 0) return hipSuccess;
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanSieve) {
-        hipExtLaunchKernelGGL(demod_tiles_sieve, dim3(a.tile_count), dim3(kSvThreads), 0, s, e0, e1, 0, a);
+        uint32_t grid = a.tile_count;
+        if (kSievePersistent) { // four workgroups per CU (39 KB of LDS each), each loops over its share of the tiles
+            static int sieve_slots = 0;
+            if (sieve_slots == 0) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+                sieve_slots = cus * 4;
+            }
+            if (grid > (uint32_t)sieve_slots) grid = (uint32_t)sieve_slots;
+        }
+        hipExtLaunchKernelGGL(demod_tiles_sieve, dim3(grid), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
 #if ADSB_AB_KERNELS

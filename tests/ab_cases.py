@@ -11,7 +11,7 @@ import air_rs_amd as A
 
 pytestmark = pytest.mark.gpu
 SCAN = os.environ.get("ADSB_SCAN", "")
-TILE = 16128 if SCAN == "reg" else 8192 if SCAN == "sieve" else 16384
+TILE = 16128 if SCAN == "reg" else 16384
 
 
 def _eq(got, want):
