@@ -243,7 +243,7 @@ extern "C" int adsb_create(const adsb_cfg *cfg, adsb_ctx **out_ctx)
         else if (strcmp(sc, "sieve") == 0) c->scan = adsbk::kScanSieve;
         else { delete c; return ADSB_E_ARG; }
         // (the A/B kernels exist only in -DADSB_AB_KERNELS=1 builds: asking this library for one it does not have is an error)
-        if (c->scan != adsbk::kScanRoot && c->scan != adsbk::kScanSieve && !adsbk::ab_kernels_built()) { delete c; return ADSB_E_ARG; }
+        if (c->scan != adsbk::kScanRoot && !adsbk::ab_kernels_built()) { delete c; return ADSB_E_ARG; }
     }
     if (cfg->sample_type != ADSB_SAMPLE_I8) c->scan = adsbk::kScanRoot; // (CS16 has one scan kernel)
     uint64_t tiles = (uint64_t)tiles_for(cfg->max_samples, cfg->sample_type, c->scan) * cfg->max_channels;

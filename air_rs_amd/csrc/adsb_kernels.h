@@ -46,6 +46,9 @@ constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2, kScanCode = 3, kScanSie
 //   kScanCode: the gate slides over an 8-bit LOG code of n = I^2+Q^2 (one quarter-rate v_cvt_pk_fp8_f32 per pair of samples
 //              instead of a root per sample); a superset test on codes, the few uncertain survivors are decided from the
 //              samples themselves (adsb_kernels.hip, "the code scan"): the product's kernel since round 4
+//   kScanSieve: one pair of relation bits per sample (neighbouring samples compared, no root), the gate's fourteen adjacent taps as
+//              shifts and ANDs of 64-bit words, the few candidates decided exactly from the raw samples kept in LDS
+//              (adsb_sieve.inc): the round-4 A/B kernel (bit-exact, 0.200 ms against the root scan's 0.190)
 //   kScanReg : the nsq gate from registers, no LDS image (every wave a chunk of 4032 offsets; window overlap by DPP from
 //              the neighbouring lane); tiles of 16128 offsets
 constexpr int kRegTile = 4 * 2 * 63 * 32; // offsets per tile of the register scan: four waves x 4032

@@ -2621,8 +2621,8 @@ hipError_t launch_small(hipStream_t s, int sample_type, int mag_mode, int scan, 
     if (p.tile_count == 0 || p.tile_count > (uint32_t)kFinTiles) return hipErrorInvalidValue;
     dim3 grid(p.tile_count), block(kThreads);
     if (sample_type == ADSB_SAMPLE_I16) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I16, 0, kScanRoot>), grid, block, 0, s, p, f, sm);
-    else if (scan == kScanSieve) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanSieve>), grid, block, 0, s, p, f, sm);
 #if ADSB_AB_KERNELS
+    else if (scan == kScanSieve) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanSieve>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanNsq) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanNsq>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanReg) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanReg>), grid, block, 0, s, p, f, sm);
     else if (scan == kScanCode) hipLaunchKernelGGL((demod_small<ADSB_SAMPLE_I8, 0, kScanCode>), grid, block, 0, s, p, f, sm);
@@ -2677,21 +2677,11 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
                         hipEvent_t e0, hipEvent_t e1)
 {
     if (a.tile_count == 0) return hipSuccess;
+#if ADSB_AB_KERNELS
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanSieve) {
-        uint32_t grid = a.tile_count;
-        if (kSievePersistent) { // four workgroups per CU (39 KB of LDS each), each loops over its share of the tiles
-            static int sieve_slots = 0;
-            if (sieve_slots == 0) {
-                int dev = 0, cus = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-                sieve_slots = cus * 4;
-            }
-            if (grid > (uint32_t)sieve_slots) grid = (uint32_t)sieve_slots;
-        }
-        hipExtLaunchKernelGGL(demod_tiles_sieve, dim3(grid), dim3(kThreads), 0, s, e0, e1, 0, a);
+        hipExtLaunchKernelGGL(demod_tiles_sieve, dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
-#if ADSB_AB_KERNELS
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
         hipExtLaunchKernelGGL((demod_tiles<ADSB_SAMPLE_I8, 0, kScanNsq>), dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
@@ -2705,7 +2695,7 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
         return hipGetLastError();
     }
 #else
-    if (sample_type == ADSB_SAMPLE_I8 && scan != kScanRoot && scan != kScanSieve) return hipErrorInvalidValue; // (the A/B kernels are not in this build)
+    if (sample_type == ADSB_SAMPLE_I8 && scan != kScanRoot) return hipErrorInvalidValue; // (the A/B kernels are not in this build)
 #endif
     if (sample_type == ADSB_SAMPLE_I8) return launch_demod_st<ADSB_SAMPLE_I8>(s, mag_mode, a, a.tile_count, e0, e1);
     return launch_demod_st<ADSB_SAMPLE_I16>(s, 0, a, a.tile_count, e0, e1);

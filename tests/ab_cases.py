@@ -1,4 +1,4 @@
-"""Parity cases for the A/B scan kernels (code, nsq, reg), run by tests/test_gpu_ab_kernels.py in a subprocess whose
+"""Parity cases for the A/B scan kernels (code, nsq, reg, sieve), run by tests/test_gpu_ab_kernels.py in a subprocess whose
 ADSB_HIP_LIB points at the -DADSB_AB_KERNELS=1 build (air_rs_amd/lib/variants/libadsb_hip_ab.so) and whose ADSB_SCAN names
 the kernel under test.  Not collected by the default run (the file name does not match test_*.py): the product library has
 none of these kernels.  Same bar as everywhere: bit-exact against the CPU oracle, through the C ABI."""

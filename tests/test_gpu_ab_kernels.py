@@ -1,4 +1,4 @@
-"""One parity run per A/B scan kernel (code, nsq, reg) through the -DADSB_AB_KERNELS=1 build of the library.
+"""One parity run per A/B scan kernel (code, nsq, reg, sieve) through the -DADSB_AB_KERNELS=1 build of the library.
 
 The product library (air_rs_amd/lib/libadsb_hip.so) carries ONE i8 scan kernel; the kernels round 3-4 measured against it
 are compiled into air_rs_amd/lib/variants/libadsb_hip_ab.so only (build.sh).  A process loads one library, so each kernel's
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AB_LIB = os.path.join(ROOT, "air_rs_amd", "lib", "variants", "libadsb_hip_ab.so")
 
 
-@pytest.mark.parametrize("scan", ["code", "nsq", "reg"])
+@pytest.mark.parametrize("scan", ["code", "nsq", "reg", "sieve"])
 def test_ab_kernel_parity(gpu, scan):
     assert os.path.exists(AB_LIB), "build.sh builds it next to the product library"
     env = dict(os.environ, ADSB_HIP_LIB=AB_LIB, ADSB_SCAN=scan)
