@@ -364,7 +364,7 @@ def main():
             try:
                 pj = json.load(open(pmc))
                 rows = {("i8", "root"): pj["i8"], ("i16", "root"): pj["cs16"], ("i8", "code"): pj.get("i8_code_scan"),
-                        ("i8", "nsq"): pj.get("i8_nsq_scan"), ("i8", "reg"): pj.get("i8_reg_scan")}
+                        ("i8", "nsq"): pj.get("i8_nsq_scan"), ("i8", "reg"): pj.get("i8_reg_scan"), ("i8", "sieve"): pj.get("i8_sieve_scan")}
                 row = rows.get((args.sample_type, dem.scan))
                 drv = row["demod_tiles"]["derived"] if row else None
                 if drv:

@@ -40,6 +40,8 @@ reg_path = os.path.join(G, "r_pmc_summary_reg.json")
 reg = json.load(open(reg_path)) if os.path.exists(reg_path) else None
 code_path = os.path.join(G, "r_pmc_summary_code.json")
 code = json.load(open(code_path)) if os.path.exists(code_path) else None
+sieve_path = os.path.join(G, "r_pmc_summary_sieve.json")
+sieve = json.load(open(sieve_path)) if os.path.exists(sieve_path) else None
 old = json.load(open(os.path.join(P, "pmc_summary.json")))
 before = old.get("before_the_split") or {"note": "demod_tiles with the whole decode inside (round 1 .. mid round 2)",
                                          "i8": old.get("i8", {}).get("demod_tiles", {}).get("derived"),
@@ -68,6 +70,9 @@ new = {
     "i8_reg_scan": ({"demod_tiles": {"derived": derived(reg["demod_tiles"], 1 << 29, 2), "raw": reg["demod_tiles"]}} if reg else None),
     # the code scan (round 4, ADSB_SCAN=code in the -DADSB_AB_KERNELS=1 build: the gate on an 8-bit log code of I^2+Q^2, no root per sample)
     "i8_code_scan": ({"demod_tiles": {"derived": derived(code["demod_tiles"], 1 << 29, 2), "raw": code["demod_tiles"]}} if code else None),
+    # the sieve scan (round 4, ADSB_SCAN=sieve in the A/B build: two relation bits per sample, the gate's adjacent taps on 64-bit words,
+    # candidates decided exactly from a raw image in LDS -- four workgroups per CU; adsb_sieve.inc)
+    "i8_sieve_scan": ({"demod_tiles": {"derived": derived(sieve["demod_tiles"], 1 << 29, 2), "raw": sieve["demod_tiles"]}} if sieve else None),
     "before_the_split": before,
     # the scan kernel's PMC rows as it was trimmed after the split (each measured by the same passes, one MI355X box each)
     "demod_tiles_i8_history": [
@@ -88,7 +93,7 @@ new = {
     ],
 }
 json.dump(new, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
-for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"), ("r_bench_reg.json", "bench_reg_scan.json"), ("r_bench_code.json", "bench_code_scan.json"),
+for src, dst in (("r_bench.json", "bench.json"), ("r_bench_driver_flags.json", "bench_driver_flags.json"), ("r_bench_nsq.json", "bench_nsq_scan.json"), ("r_bench_reg.json", "bench_reg_scan.json"), ("r_bench_code.json", "bench_code_scan.json"), ("r_bench_sieve.json", "bench_sieve_scan.json"),
                  ("r_feed_bench.txt", "feed_bench.txt"), ("r_bench_cs16.json", "bench_cs16.json"), ("r_bench_16g.json", "bench_16GiB.json"),
                  ("r_bench_cs16_16g.json", "bench_cs16_16GiB.json"), ("r_bench_64ch.json", "bench_64_channels.json"),
                  ("r_kernel_stats.csv", "kernel_stats.csv"), ("prof_bench.json", "bench_under_rocprofv3.json"), ("r_kernel_stats_16g.csv", "kernel_stats_16GiB.csv")):
