@@ -12,7 +12,7 @@ from tests.oracle_binding import Oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
-ap.add_argument("--scans", default="root", help="i8 scan kernels to soak (the A/B build also has code,nsq,reg)")
+ap.add_argument("--scans", default="root", help="i8 scan kernels to soak (the A/B build also has code,nsq,reg,sieve)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 orc = Oracle()
@@ -22,7 +22,7 @@ def make(st, max_samples, max_out, scan="root", small_path="1"):
 
 
 # every kernel the loaded library carries: i8 root scan (the product's; with ADSB_HIP_LIB pointing at the -DADSB_AB_KERNELS=1
-# build and --scans root,code,nsq,reg also the A/B kernels), CS16; the one-dispatch path for small buffers on (default) and
+# build and --scans root,code,nsq,reg,sieve also the A/B kernels), CS16; the one-dispatch path for small buffers on (default) and
 # off; and small frame capacities (dense inputs overflow the slot pool and are re-planned)
 SCANS = args.scans.split(",")
 ctx = {(A.ADSB_SAMPLE_I16, "root"): make(A.ADSB_SAMPLE_I16, 1 << 22, 1 << 19),
