@@ -2679,7 +2679,17 @@ hipError_t launch_demod(hipStream_t s, int sample_type, int mag_mode, int scan, 
     if (a.tile_count == 0) return hipSuccess;
 #if ADSB_AB_KERNELS
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanSieve) {
-        hipExtLaunchKernelGGL(demod_tiles_sieve, dim3(a.tile_count), dim3(kThreads), 0, s, e0, e1, 0, a);
+        uint32_t grid = a.tile_count;
+        if (kSievePersistent) { // (A/B) four workgroups per CU, each loops over its share of the tiles
+            static int sieve_slots = 0;
+            if (sieve_slots == 0) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+                sieve_slots = cus * 4;
+            }
+            if (grid > (uint32_t)sieve_slots) grid = (uint32_t)sieve_slots;
+        }
+        hipExtLaunchKernelGGL(demod_tiles_sieve, dim3(grid), dim3(kThreads), 0, s, e0, e1, 0, a);
         return hipGetLastError();
     }
     if (sample_type == ADSB_SAMPLE_I8 && scan == kScanNsq) {
