@@ -52,10 +52,15 @@ constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2, kScanCode = 3, kScanSie
 //   kScanReg : the nsq gate from registers, no LDS image (every wave a chunk of 4032 offsets; window overlap by DPP from
 //              the neighbouring lane); tiles of 16128 offsets
 constexpr int kRegTile = 4 * 2 * 63 * 32; // offsets per tile of the register scan: four waves x 4032
+#ifndef ADSB_SV_SWEEPS
+#define ADSB_SV_SWEEPS 8                  // 16-byte loads per lane and tile of the sieve scan (8: 16384-offset tiles, four workgroups
+#endif                                    // per CU; 6: 12288, five -- measured no faster, profiles/r04_ab_sieve.txt)
+constexpr int kSieveTile = ADSB_SV_SWEEPS * kThreads * 8; // offsets per tile of the sieve scan (adsb_sieve.inc)
 // offsets per tile of a context (the scan kind is fixed at adsb_create)
 constexpr int tile_offsets_of(int sample_type, int scan)
 {
-    return (sample_type == ADSB_SAMPLE_I8 && scan == kScanReg) ? kRegTile : tile_offsets(sample_type);
+    return (sample_type == ADSB_SAMPLE_I8 && scan == kScanReg) ? kRegTile
+           : (sample_type == ADSB_SAMPLE_I8 && scan == kScanSieve) ? kSieveTile : tile_offsets(sample_type);
 }
 constexpr int kListCap = 128;   // candidate offsets staged per decode chunk
 constexpr int kSparseCap = 64;  // up to this many gate survivors per tile take the cheap (rank-sort) path
