@@ -66,3 +66,21 @@ def test_gate_implies_all_fourteen_taps():
     assert gate.sum() > 300                       # the planted frames
     assert not (gate & ~cand).any()               # the sieve loses none of them
     assert cand.sum() < 12 * gate.sum()           # ... and lets a handful per tile through besides
+
+
+def test_tap_algebra_on_words_equals_the_fourteen_taps():
+    """sv_taps (adsb_sieve.inc): Y = L & G>>1, Z = Y & Y>>2, A = G & Y>>1, P = A & Z>>6 & G>>16 & Z>>18 & L>>22 & G>>24 on a 96-bit
+    window, restated on Python integers, against the fourteen taps evaluated one by one."""
+    rng = np.random.default_rng(11)
+    m96 = (1 << 96) - 1
+    for _ in range(2000):
+        # biased bits: mostly ones, so that all fourteen taps coincide often enough to be seen
+        g = sum(int(b) << i for i, b in enumerate(rng.random(96) < 0.9))
+        l = sum(int(b) << i for i, b in enumerate(rng.random(96) < 0.9))
+        y = l & (g >> 1)
+        z = y & (y >> 2)
+        a = g & (y >> 1)
+        p = a & (z >> 6) & (g >> 16) & (z >> 18) & (l >> 22) & (g >> 24) & m96
+        for i in range(64):
+            want = all((g >> (i + d)) & 1 for d in G_TAPS) and all((l >> (i + d)) & 1 for d in L_TAPS)
+            assert ((p >> i) & 1) == int(want)
