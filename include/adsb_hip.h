@@ -359,10 +359,10 @@ int adsb_debug_nsq_values(adsb_ctx *ctx, const void *iq_host, size_t n_samples, 
  * of the survivors) but not the finishing kernel -- no survivor is CRC-checked, the header reports an empty list, so
  * NO frames come out.  on = 0 restores the full path. */
 int adsb_debug_fused_pass_only(adsb_ctx *ctx, int on);
-/* Which scan kernel an i8 context launches: 3 = the code scan (default since round 4: the gate slides over an 8-bit log
- * code of I^2+Q^2, uncertain survivors are decided from the samples themselves); 1 = floor(sqrt) per sample
- * (ADSB_SCAN=root in the environment at adsb_create); 0 / 2 = the round-3 A/B kernels (ADSB_SCAN=nsq / reg; only in
- * builds with -DADSB_AB_KERNELS=1).  Same results; DESIGN.md has the measurements.  Always 1 for CS16 (one kernel). */
+/* Which scan kernel an i8 context launches: 1 = floor(sqrt) per sample, the product's and the default (ADSB_SCAN=root or
+ * unset in the environment at adsb_create); 0 / 2 / 3 / 4 = the A/B kernels of rounds 3-4 (ADSB_SCAN=nsq / reg / code / sieve;
+ * only in builds with -DADSB_AB_KERNELS=1: the gate on I^2+Q^2, the same from registers, on an 8-bit log code, on two relation
+ * bits per sample).  Same results; DESIGN.md sections 4.1b-d have the measurements.  Always 1 for CS16 (one kernel). */
 int adsb_debug_scan(adsb_ctx *ctx);
 /* The code scan's table as this device computes it, for n = I^2+Q^2 = 0 .. 32768: out[n] = c(n) | th(n) << 8 (c = the
  * 8-bit code of n, th = the threshold code of the gate's slack for a "high" of that code).  Returns ADSB_E_STATE if the
