@@ -45,7 +45,7 @@ constexpr int kTileMax = kTile > 2 * kThreads * kRunI16 ? kTile : 2 * kThreads *
 constexpr int kScanNsq = 0, kScanRoot = 1, kScanReg = 2, kScanCode = 3, kScanSieve = 4;
 //   kScanCode: the gate slides over an 8-bit LOG code of n = I^2+Q^2 (one quarter-rate v_cvt_pk_fp8_f32 per pair of samples
 //              instead of a root per sample); a superset test on codes, the few uncertain survivors are decided from the
-//              samples themselves (adsb_kernels.hip, "the code scan"): the product's kernel since round 4
+//              samples themselves (adsb_kernels.hip, "the code scan"): a round-4 A/B kernel (bit-exact, not faster)
 //   kScanSieve: one pair of relation bits per sample (neighbouring samples compared, no root), the gate's fourteen adjacent taps as
 //              shifts and ANDs of 64-bit words, the few candidates decided exactly from the raw samples kept in LDS
 //              (adsb_sieve.inc): the round-4 A/B kernel (bit-exact, 0.200 ms against the root scan's 0.190)

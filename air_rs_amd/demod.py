@@ -166,9 +166,9 @@ class AdsbDemod:
 
     @property
     def scan(self):
-        """Which scan kernel this context launches (fixed at adsb_create by ADSB_SCAN): 'code' (the default for i8: the gate
-        on an 8-bit log code of I^2+Q^2), 'root' (floor(sqrt) per sample, u8 magnitudes in LDS; CS16's only one), 'nsq' /
-        'reg' (the round-3 A/B kernels, in -DADSB_AB_KERNELS=1 builds only)."""
+        """Which scan kernel this context launches (fixed at adsb_create by ADSB_SCAN): 'root' (floor(sqrt) per sample, u8
+        magnitudes in LDS: the product's, the default; CS16's only one), or one of the A/B kernels of rounds 3-4, in
+        -DADSB_AB_KERNELS=1 builds only: 'nsq', 'reg', 'code', 'sieve' (DESIGN.md sections 4.1b-d)."""
         return {0: "nsq", 1: "root", 2: "reg", 3: "code", 4: "sieve"}[self._lib.adsb_debug_scan(self._h)]
 
     def code_table(self):

@@ -47,9 +47,9 @@ def parse_args(argv=None):
                     help="split the per-GPU buffer into this many independent channels handled by ONE launch "
                          "(BASELINE configs[3]: 64); the default 1 is the metric's workload")
     ap.add_argument("--scan", choices=["default", "code", "root", "nsq", "reg", "sieve"], default="default",
-                    help="i8 scan kernel: code = the gate on an 8-bit log code of I^2+Q^2 (the product's since round 4), root = "
-                         "floor(sqrt) per sample (round 1-3's), nsq / reg = the round-3 A/B kernels (-DADSB_AB_KERNELS=1 builds "
-                         "only); default = the library's default (ADSB_SCAN in the environment is honoured)")
+                    help="i8 scan kernel: root = floor(sqrt) per sample (the product's); code / nsq / reg / sieve = the A/B kernels of "
+                         "rounds 3-4 (-DADSB_AB_KERNELS=1 builds only: point ADSB_HIP_LIB at air_rs_amd/lib/variants/libadsb_hip_ab.so); "
+                         "default = the library's default (ADSB_SCAN in the environment is honoured)")
     ap.add_argument("--force-gather", action="store_true",
                     help="exercise the multi-rank frame-list gather even with one rank (testing)")
     ap.add_argument("--no-feed", action="store_true", help="skip the PCIe-inclusive feed measurement after the timed region")
