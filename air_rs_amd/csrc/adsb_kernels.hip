@@ -1302,11 +1302,31 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
+// Which tile a workgroup takes.  The dispatcher deals workgroups to the eight XCDs round-robin (workgroup b runs on XCD b mod 8)
+// and each XCD has its own L2: with tile = b, a tile's 240-sample halo -- the first samples of the NEXT tile -- is fetched by two
+// different XCDs, i.e. twice from HBM (FETCH_SIZE = 1.016 x the buffer for i8, 1.031 x for CS16: exactly the halos).  With the
+// launch's tiles cut into eight contiguous ranges, XCD x walking range x in order, neighbouring tiles run on the same XCD at about
+// the same time and the halo is an L2 hit.  (n = 8 q + r tiles: XCD x owns q + (x < r) of them, starting at x q + min(x, r); b =
+// 8 j + x < n picks the j-th.)
+#ifndef ADSB_XCD_MAP
+#define ADSB_XCD_MAP 1
+#endif
+__device__ __forceinline__ uint32_t tile_of_workgroup(uint32_t b, uint32_t n)
+{
+#if ADSB_XCD_MAP
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u, j = b >> 3;
+    return x * q + (x < r ? x : r) + j;
+#else
+    (void)n;
+    return b;
+#endif
+}
+
 template <int ST, int MAGMODE, int SCAN>
 __global__ __launch_bounds__(kThreads, (ST == ADSB_SAMPLE_I8 && SCAN == kScanRoot) ? 8 : ADSB_SCAN_WAVES) void demod_tiles(DemodArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[Lds<ST, SCAN>::kTotal];
-    scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    scan_tile<ST, MAGMODE, SCAN>(p, p.tile_first + tile_of_workgroup(blockIdx.x, p.tile_count), blockIdx.x == 0, smem);
 }
 
 // ---- CRC-24 + single-bit repair of the sliced survivors (demod.rs:71-81; crc.rs:10-65) --------------------------
