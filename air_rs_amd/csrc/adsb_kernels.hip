@@ -14,7 +14,8 @@
 // DESIGN.md section 5).  A launch is two kernels:
 //   demod_tiles (the SCAN: every IQ byte is read once)
 //   * one workgroup = one tile of kTile offsets; the tile's raw IQ is read coalesced, 16 B per lane, all loads in flight
-//     before the first use, through a bounds-checked buffer descriptor (tails read as zero);
+//     before the first use, through a bounds-checked buffer descriptor (tails read as zero); which tile a workgroup takes is
+//     XCD-aware (tile_of_workgroup: eight contiguous ranges of tiles, one per XCD, so a tile's halo is an L2 hit);
 //   * phase 1: magnitudes in registers (v_dot4_i32_i8 -> v_sqrt_f32 -> v_cvt_pk_u8_f32), parked in LDS as u8 (i8 input)
 //     or u16 (CS16);
 //   * phase 2: the gate runs "transposed": each lane slides along its own run of kRun consecutive offsets, two runs
@@ -32,7 +33,7 @@
 // Buffers of at most 32 tiles (the reference's own 20 000-sample buffers) take ONE dispatch (demod_small: the tile body
 // per workgroup, the last workgroup to arrive runs the finishing block and writes into pinned host memory).
 // The product library carries one i8 scan (kScanRoot) and CS16's; the kernels measured against it (kScanNsq, kScanReg,
-// kScanCode: bit-exact, none faster) are compiled with -DADSB_AB_KERNELS=1 only.
+// kScanCode, kScanSieve: bit-exact, none faster) are compiled with -DADSB_AB_KERNELS=1 only.
 #include <hip/hip_ext.h>
 #include <utility>
 #include <cstdlib>
@@ -2070,7 +2071,7 @@ __device__ __forceinline__ void scan_tile_reg(const DemodArgs &p, const uint32_t
 __global__ __launch_bounds__(kThreads, ADSB_REG_WAVES) void demod_tiles_reg(DemodArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RegLds::kTotal];
-    scan_tile_reg(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    scan_tile_reg(p, p.tile_first + tile_of_workgroup(blockIdx.x, p.tile_count), blockIdx.x == 0, smem);
 }
 #endif
 
@@ -2581,7 +2582,7 @@ __device__ __forceinline__ void scan_tile_code(const DemodArgs &p, const uint32_
 __global__ __launch_bounds__(kThreads, 8) void demod_tiles_code(DemodArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CodeLds::kTotal];
-    scan_tile_code(p, p.tile_first + blockIdx.x, blockIdx.x == 0, smem);
+    scan_tile_code(p, p.tile_first + tile_of_workgroup(blockIdx.x, p.tile_count), blockIdx.x == 0, smem);
 }
 #endif
 
