@@ -972,16 +972,21 @@ extern "C" int adsb_time_read_ceiling(adsb_ctx *c, const void *buf_dev, size_t b
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    HIPCHK(adsbk::launch_read_only(c->stream, buf_dev, bytes, c->scratch + 8)); // warm-up
-    HIPCHK(hipEventRecord(e0, c->stream));
-    for (int k = 0; k < iters; ++k) HIPCHK(adsbk::launch_read_only(c->stream, buf_dev, bytes, c->scratch + 8));
-    HIPCHK(hipEventRecord(e1, c->stream));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    // the fastest of the read shapes (adsb_kernels.hip, read_only_kernel): none of them wins on every box and size
+    double best = 0;
+    for (int shape = 0; shape < adsbk::kReadShapes; ++shape) {
+        HIPCHK(adsbk::launch_read_only(c->stream, buf_dev, bytes, c->scratch + 8, shape)); // warm-up
+        HIPCHK(hipEventRecord(e0, c->stream));
+        for (int k = 0; k < iters; ++k) HIPCHK(adsbk::launch_read_only(c->stream, buf_dev, bytes, c->scratch + 8, shape));
+        HIPCHK(hipEventRecord(e1, c->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (shape == 0 || (double)ms / iters < best) best = (double)ms / iters;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    *ms_per_pass = (double)ms / iters;
+    *ms_per_pass = best;
     return ADSB_OK;
 }
 

@@ -185,7 +185,8 @@ hipError_t launch_magnitudes(hipStream_t s, int sample_type, int mag_mode, const
                              size_t n, uint16_t *out);
 // i8: the biased squared magnitudes I^2+Q^2+72 as the nsq scan kernel's phase 1 packs them (test hook)
 hipError_t launch_nsq_values(hipStream_t s, const void *iq, size_t n, uint16_t *out);
-hipError_t launch_read_only(hipStream_t s, const void *buf, size_t bytes, uint32_t *sink);
+hipError_t launch_read_only(hipStream_t s, const void *buf, size_t bytes, uint32_t *sink, int shape); // shape 0..2 (kReadShapes)
+constexpr int kReadShapes = 3;
 hipError_t launch_synth(hipStream_t s, const adsb_synth_cfg &cfg, int sample_type,
                         uint32_t channel, uint64_t first, size_t n, void *iq);
 

@@ -2869,31 +2869,41 @@ hipError_t launch_nsq_values(hipStream_t s, const void *iq, size_t n, uint16_t *
     return hipGetLastError();
 }
 
-// Pure streaming read in the tile kernel's own access shape: one workgroup per 64 KB, 16 loads of 16 bytes per
-// lane, all in flight before the first use, `nt` policy; the values are only XOR-ed.  What this box's HBM
-// delivers to a kernel that does nothing else with the bytes (the grid-stride, default-policy loop this
-// replaced read 15 % slower than the tile kernel's own phase 1 and so was no ceiling).
-__global__ __launch_bounds__(256) void read_only_kernel(const u32x4 *buf, size_t n16, uint32_t *sink)
+// Pure streaming read: LOADS loads of 16 bytes per lane, all in flight before the first use, `nt` policy, one workgroup per
+// LOADS x 4 KB; the values are only XOR-ed.  What this box's HBM delivers to a kernel that does nothing else with the bytes.  No
+// single shape is the fastest on every box and size (tools/ubench/read_shapes.hip, profiles/r04_read_shapes.txt: 6.8-7.1 TB/s
+// at 1 GiB, 7.0-7.2 at 16 GiB; the 16-load shape in plain workgroup order, the only one until round 4, is the slowest at 1 GiB
+// by 3-4 %), so adsb_time_read_ceiling times three -- shape 0: 4 loads, 1: 8 loads, 2: 16 loads with the chunks dealt to
+// workgroups in eight contiguous ranges like the scan's tiles -- and reports the fastest.
+template <int LOADS, bool XCD>
+__global__ __launch_bounds__(256) void read_only_kernel(const u32x4 *buf, size_t n16, uint32_t n_wg, uint32_t *sink)
 {
-    const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
-    u32x4 v[16];
+    const uint32_t b = XCD ? tile_of_workgroup(blockIdx.x, n_wg) : blockIdx.x;
+    const size_t base = (size_t)b * (256 * LOADS) + threadIdx.x;
+    u32x4 v[LOADS];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < LOADS; ++k) {
         const size_t i = base + (size_t)k * 256;
         v[k] = i < n16 ? __builtin_nontemporal_load(buf + i) : u32x4{0u, 0u, 0u, 0u};
     }
     uint32_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    for (int k = 0; k < LOADS; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
     if (acc == 0x9E3779B9u) *sink = acc; // practically never: keeps the loads alive
 }
 
-hipError_t launch_read_only(hipStream_t s, const void *buf, size_t bytes, uint32_t *sink)
+hipError_t launch_read_only(hipStream_t s, const void *buf, size_t bytes, uint32_t *sink, int shape)
 {
     const size_t n16 = bytes / 16;
     if (n16 == 0) return hipSuccess;
-    hipLaunchKernelGGL(read_only_kernel, dim3((unsigned)((n16 + 4095) / 4096)), dim3(256), 0, s,
-                       reinterpret_cast<const u32x4 *>(buf), n16, sink);
+    const int loads = shape == 0 ? 4 : shape == 1 ? 8 : 16;
+    const size_t per_wg = (size_t)256 * loads;
+    const uint32_t n_wg = (uint32_t)((n16 + per_wg - 1) / per_wg);
+    const u32x4 *b = reinterpret_cast<const u32x4 *>(buf);
+    if (shape == 0) hipLaunchKernelGGL((read_only_kernel<4, false>), dim3(n_wg), dim3(256), 0, s, b, n16, n_wg, sink);
+    else if (shape == 1) hipLaunchKernelGGL((read_only_kernel<8, false>), dim3(n_wg), dim3(256), 0, s, b, n16, n_wg, sink);
+    else if (shape == 2) hipLaunchKernelGGL((read_only_kernel<16, true>), dim3(n_wg), dim3(256), 0, s, b, n16, n_wg, sink);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -333,8 +333,9 @@ int adsb_timing_read3(adsb_ctx *ctx, double *scan_ms_mean, double *decode_ms_mea
                       uint32_t *n_launches);
 int adsb_timing_read(adsb_ctx *ctx, double *demod_ms_mean, double *order_ms_mean,
                      uint32_t *n_launches);
-/* Pure-read HBM ceiling on this device: streams `bytes` from `buf_dev` `iters` times with 16-byte
- * loads and returns the mean milliseconds per pass. */
+/* Pure-read HBM ceiling on this device: streams `bytes` from `buf_dev` `iters` times with 16-byte loads in each of three
+ * access shapes (4 / 8 / 16 loads in flight per lane; no shape is the fastest on every box and size) and returns the mean
+ * milliseconds per pass of the fastest. */
 int adsb_time_read_ceiling(adsb_ctx *ctx, const void *buf_dev, size_t bytes, int iters,
                            double *ms_per_pass);
 /* Measurement: what one buffer costs when it comes from HOST memory through the streaming front end (adsb_feed_*, defined
