@@ -1303,7 +1303,8 @@ __device__ __forceinline__ void scan_tile(const DemodArgs &p, const uint32_t til
     if (!NSQ && MAGMODE == 1) __builtin_amdgcn_s_setreg((1 | (0 << 6) | ((2 - 1) << 11)), 0);
 }
 
-// Which tile a workgroup takes.  The dispatcher deals workgroups to the eight XCDs round-robin (workgroup b runs on XCD b mod 8)
+// Which tile a workgroup takes.  The dispatcher deals workgroups to the eight XCDs round-robin (workgroup b runs on XCD b mod 8:
+// tools/ubench/xcc_probe.hip reads HW_REG_XCC_ID in every workgroup, profiles/r04_xcc_probe.txt)
 // and each XCD has its own L2: with tile = b, a tile's 240-sample halo -- the first samples of the NEXT tile -- is fetched by two
 // different XCDs, i.e. twice from HBM (FETCH_SIZE = 1.016 x the buffer for i8, 1.031 x for CS16: exactly the halos).  With the
 // launch's tiles cut into eight contiguous ranges, XCD x walking range x in order, neighbouring tiles run on the same XCD at about
